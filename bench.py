@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the GNN.Loop hot path on MI355X (BASELINE.json metric: node-state-updates/s).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]): synthetic graph with 1,000,000 nodes and ~10,000,000 directed arcs
+(randomGraph recipe, 'average' aggregation), state_dim 64, node/arc labels 3/1, net_state 135->128->128->64 selu +
+BatchNormalization, net_output 67->2 softmax + BatchNormalization, injected N(0, 0.1^2) initial state, threshold 0 so
+that every Loop runs exactly max_iteration = 30 iterations.  One "step" = one GNN.Loop (condition, 30 x convergence,
+apply_filters, net_output).  Graph, weights and initial state are resident in HBM before the timed region.
+
+With N > 1 the SAME graph is sharded by node range (strong scaling): each rank owns N/P destination rows, and every
+iteration ends with one grouped RCCL all-gather of the owned state rows + convergence flag.  No torch in the process: ranks
+read RANK / LOCAL_RANK / WORLD_SIZE from the environment and exchange the RCCL id through a file keyed by the launcher.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'gnn_tf_2.x_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_net(rng, n_in, widths, act, out_act=None):
+    """Random-init weights of the architecture (lecun_normal-like scale, as starter.py:52-54), BatchNormalization defaults."""
+    w, acts = [], []
+    for i, u in enumerate(widths):
+        w += [(rng.standard_normal((n_in, u)) / np.sqrt(n_in)).astype(np.float32), (rng.standard_normal(u) / np.sqrt(u)).astype(np.float32) * 0.1]
+        acts.append(out_act if (out_act and i == len(widths) - 1) else act)
+        n_in = u
+    w += [np.ones(n_in, np.float32), np.zeros(n_in, np.float32), np.zeros(n_in, np.float32), np.ones(n_in, np.float32)]
+    return dict(weights=w, activations=acts, batch_normalization=True)
+
+
+def algorithmic_bytes_per_iteration(n, e, ds, nl, al):
+    """fp32 values, int32 indices, no cache credit for neighbour rows, fused iteration (no concat / aggregate
+    materialised): E(4 Ds + 4 + 4) + 4(N + 1) + N(4 Ds read + 4 Ds write + 4(2 NL + AL) invariant label terms)."""
+    return e * (4 * ds + 8) + 4 * (n + 1) + n * (8 * ds + 4 * (2 * nl + al))
+
+
+def rendezvous_id(rank, world, engine):
+    """Rank 0 creates the RCCL unique id; the others read it from a file keyed by the launcher process (same parent)."""
+    ppid = os.getppid()
+    try:
+        with open(f'/proc/{ppid}/stat') as f:
+            start = f.read().rsplit(')', 1)[1].split()[19]
+    except Exception:
+        start = '0'
+    path = f'/tmp/gnn_rccl_{ppid}_{start}_{os.environ.get("MASTER_PORT", "0")}_{world}.id'
+    if rank == 0:
+        uid = engine.Comm.unique_id()
+        with open(path + '.tmp', 'wb') as f:
+            f.write(uid)
+        os.replace(path + '.tmp', path)
+        return uid, path
+    deadline = time.time() + 300
+    while not os.path.exists(path):
+        if time.time() > deadline:
+            raise RuntimeError(f'rank {rank}: timed out waiting for {path}')
+        time.sleep(0.05)
+    with open(path, 'rb') as f:
+        return f.read(), path
+
+
+def cpu_baseline(s, st, ou, state0, d, iters):
+    """The plain-C restatement of the TF2 op sequence (oracle/gnn_oracle.c: CSR SpMM -> materialised concat -> Dense x3 ->
+    BatchNormalization -> norm check), OpenMP over all host cores, on a bounded sample: the full graph, `iters` iterations."""
+    from oracle import c_oracle
+    n = s['n_nodes']
+    arcs = np.concatenate([np.stack([s['src'], s['dst']], 1).astype(np.float32), s['arc_labels']], axis=1)
+    g = dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
+             adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
+    c_oracle.loop_node(g, st, ou, d, 1, 0.0, state0)     # warm-up (page faults, thread pool)
+    t = time.perf_counter()
+    k, _, _ = c_oracle.loop_node(g, st, ou, d, iters, 0.0, state0)
+    dt = time.perf_counter() - t
+    return dict(value=n * k / dt, unit='node-state-updates/s', cores=c_oracle.num_threads(), kind='port',
+                sample=f'full 1M-node graph, {int(k)} iterations + readout, C restatement of the TF2 op sequence '
+                       f'(not TensorFlow itself), OpenMP, {dt:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--nodes', type=int, default=1_000_000)
+    ap.add_argument('--arcs-per-node', type=float, default=10.0)
+    ap.add_argument('--max-iter', type=int, default=30)
+    ap.add_argument('--impl', type=int, default=1, help='1: fused kernel (default), 0: one kernel per TF op')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+
+    from GNN import _engine as engine, GNN_utils as utils
+    engine.require_device(local_rank)
+
+    d, nl, al, t = 64, 3, 1, 2
+    s = utils.syntheticGraph(args.nodes, args.arcs_per_node, nl, al, t, seed=20261003)
+    n, e = s['n_nodes'], s['n_arcs']
+    rng = np.random.default_rng(20261003)
+    st = make_net(rng, al + 2 * (nl + d), [128, 128, d], 'selu')
+    ou = make_net(rng, nl + d, [t], 'softmax')
+    state0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+
+    comm, id_path = None, None
+    if world > 1:
+        uid, id_path = rendezvous_id(rank, world, engine)
+        comm = engine.Comm(uid, rank, world, local_rank)
+    rb, nr = engine.shard_range(n, rank, world)
+    e0, e1 = int(s['indptr'][rb]), int(s['indptr'][rb + nr])
+    graph = engine.Graph(n, s['indptr'][rb:rb + nr + 1] - e0, s['adj_src'][e0:e1], s['adj_w'][e0:e1], s['arc_w'][e0:e1],
+                         s['arc_labels_csr'][e0:e1], s['nodes'], np.ones(nr, np.uint8), row_begin=rb, device=local_rank)
+    loop = engine.Loop(graph, engine.Mlp(st['weights'], st['activations'], True, device=local_rank),
+                       engine.Mlp(ou['weights'], ou['activations'], True, device=local_rank), d, args.max_iter, 0.0, comm)
+    impl_used = loop.set_impl(args.impl)
+    loop.set_state0(state0[rb:rb + nr])
+
+    def barrier(value=0.0):
+        engine._check(engine.lib().gnn_device_synchronize(local_rank))
+        return comm.allreduce_max(value) if comm else value
+
+    for _ in range(args.warmup):
+        loop.run()
+    loop.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    k_total, iter_ms = 0.0, []
+    for _ in range(args.steps):
+        k_total += loop.run()
+        iter_ms.append(loop.timing()['avg_iter_ms'])
+    elapsed = barrier(time.perf_counter() - t0)          # device sync, then max over ranks
+    loop.set_profiling(False)
+
+    if rank == 0:
+        updates = n * k_total
+        kernel_ms = float(np.mean(iter_ms))
+        alg_bytes = algorithmic_bytes_per_iteration(nr, e1 - e0, d, nl, al)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            'metric': 'node-state-updates/sec (nodes x iters / s), 1M-node synthetic graph',
+            'value': updates / elapsed, 'unit': 'node-state-updates/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'synthetic randomGraph-recipe graph, N={n} nodes, E={e} arcs, state_dim=64, '
+                                   f'net_state 135->128->128->64 selu+BN, net_output 67->2 softmax+BN, '
+                                   f'max_iter={args.max_iter}, threshold=0 (all iterations run)',
+                       'iterations_per_step': k_total / args.steps,
+                       'parallelism': f'node-range shards x{world}, RCCL all-gather of state rows per iteration' if world > 1 else 'single GPU',
+                       'impl': 'fused gather+MLP kernel' if impl_used else 'one kernel per TF op (unfused)'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None,
+                         'kernel': 'gnn_fused_iteration' if impl_used else 'spmm + dense x3 + check (sum of the per-iteration kernels)',
+                         'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': kernel_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters)
+        print(json.dumps(line), flush=True)
+    if comm:
+        barrier()
+        if rank == 0 and id_path and os.path.exists(id_path):
+            os.remove(id_path)
+
+
+if __name__ == '__main__':
+    main()

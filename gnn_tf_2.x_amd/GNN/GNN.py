@@ -1,0 +1,143 @@
+"""GNN models with the reference's public surface (``GNN/GNN.py``), running ``Loop`` on the MI355X.
+
+``Loop(g)`` = reference GNN.py:251-280: loop-invariant aggregates, iterate ``state <- net_state([state | labels |
+Adjacency^T.state | aggregated labels])`` while some node moved by more than ``threshold`` (relative L2, strict '>') and
+``k < max_iteration``, then ``net_output`` on the rows selected by ``set_mask & output_mask``.  The whole loop is one
+call into ``libgnn_hip.so`` (``gnn_loop_run``); Python only converts the graph once and copies results back.
+
+Extensions over the reference signature (needed because TensorFlow's RNG stream cannot be reproduced):
+``Loop(g, training=False, state0=None)`` takes an injected initial state for ``state_vect_dim > 0``; without it the
+engine draws N(0, 0.1^2) from its own generator seeded by ``self.seed``.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional, Union
+
+import numpy as np
+
+from GNN import _engine
+from GNN.GNN_BaseClass import BaseClass
+from GNN.MLP import Sequential, clone_model
+from GNN.graph_class import GraphObject, GraphTensor
+
+
+class GNNnodeBased(BaseClass):
+    """GNN for node-based problems."""
+
+    def __init__(self, net_state: Sequential, net_output: Sequential, optimizer, loss_function, loss_arguments: Optional[dict],
+                 state_vect_dim: int, max_iteration: int, threshold: float, addressed_problem: str,
+                 extra_metrics: Optional[dict] = None, extra_metrics_arguments: Optional[dict[str, dict]] = None,
+                 path_writer: str = 'writer/', namespace: str = 'GNN') -> None:
+        if not isinstance(state_vect_dim, int) or state_vect_dim < 0: raise TypeError('param <state_vect_dim> must be int>=0')
+        super().__init__(optimizer, loss_function, loss_arguments, addressed_problem, extra_metrics, extra_metrics_arguments,
+                         path_writer, namespace)
+        self.net_state = net_state
+        self.net_output = net_output
+        self.max_iteration = max_iteration
+        self.state_threshold = threshold
+        self.state_vect_dim = state_vect_dim
+        self.seed = 0
+        self.device = 0
+        self.impl = 1           # 1: fused kernel when the shapes allow it, 0: one kernel per TF op
+
+    # ---- copies, weights ---------------------------------------------------------------------------------------------
+    def copy(self, *, path_writer: str = '', namespace: str = '', copy_weights: bool = True):
+        optimizer = self.optimizer
+        if hasattr(optimizer, 'get_config'):
+            optimizer = optimizer.__class__(**optimizer.get_config())
+        return self.__class__(net_state=clone_model(self.net_state, copy_weights), net_output=clone_model(self.net_output, copy_weights),
+                              optimizer=optimizer, loss_function=self.loss_function, loss_arguments=self.loss_args,
+                              max_iteration=self.max_iteration, threshold=self.state_threshold,
+                              addressed_problem=self.addressed_problem, extra_metrics=self.extra_metrics,
+                              extra_metrics_arguments=self.mt_args, state_vect_dim=self.state_vect_dim,
+                              path_writer=path_writer or self.path_writer + '_copied/', namespace=namespace or 'GNN')
+
+    def save(self, path: str):
+        """net_state / net_output weights as .npz plus config.json (the reference writes Keras SavedModels, GNN.py:93-111)."""
+        import json, os
+        if path[-1] != '/': path += '/'
+        os.makedirs(path, exist_ok=True)
+        for name, net in (('net_state', self.net_state), ('net_output', self.net_output)):
+            np.savez(f'{path}{name}.npz', *net.get_weights(), activations=np.array(net.activations, dtype=object),
+                     batch_normalization=net.batch_normalization)
+        with open(f'{path}config.json', 'w') as f:
+            json.dump({'loss_arguments': self.loss_args, 'max_iteration': self.max_iteration, 'threshold': self.state_threshold,
+                       'addressed_problem': self.addressed_problem, 'state_vect_dim': self.state_vect_dim}, f)
+
+    def get_dense_layers(self):
+        return self.net_state.dense_layers + self.net_output.dense_layers
+
+    def trainable_variables(self):
+        return [self.net_state.trainable_variables], [self.net_output.trainable_variables]
+
+    def get_weights(self):
+        return [self.net_state.get_weights()], [self.net_output.get_weights()]
+
+    def set_weights(self, weights_state, weights_output) -> None:
+        assert len(weights_state) == len(weights_output) == 1
+        self.net_state.set_weights(weights_state[0])
+        self.net_output.set_weights(weights_output[0])
+
+    # ---- inference -----------------------------------------------------------------------------------------------------
+    def __call__(self, g: Union[GraphObject, GraphTensor]):
+        return self.Loop(g, training=False)[-1]
+
+    def evaluate_single_graph(self, g: Union[GraphObject, GraphTensor], training: bool) -> tuple:
+        """(iterations, summed loss, targets, output) of one graph (reference GNN.py:180-199)."""
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        targs = self.get_filtered_tensor(g, g.targets)
+        loss_weights = self.get_filtered_tensor(g, g.sample_weights)
+        it, _, out = self.Loop(g, training=training)
+        loss = self.loss_function(targs, out, **self.loss_args) * loss_weights
+        return it, np.sum(loss), targs, out
+
+    def _device_loop(self, dev_graph: _engine.Graph) -> _engine.Loop:
+        """One gnn_loop per (this model, device graph), created on first use."""
+        cache = dev_graph.__dict__.setdefault('_loops', {})
+        owner, loop = cache.get(id(self), (None, None))
+        if owner is None or owner() is not self:
+            loop = _engine.Loop(dev_graph, self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device),
+                                self.state_vect_dim, self.max_iteration, self.state_threshold)
+            cache[id(self)] = (weakref.ref(self), loop)
+        loop.set_impl(self.impl)
+        return loop
+
+    def _run(self, dev_graph: _engine.Graph, training: bool, state0) -> tuple[float, _engine.Loop]:
+        if training:
+            raise NotImplementedError('Loop(training=True): Dropout masks / BatchNormalization batch statistics and the tape for '
+                                      'back-propagation are not implemented on the MI355X engine yet')
+        loop = self._device_loop(dev_graph)
+        if self.state_vect_dim > 0:
+            loop.set_state0(state0, self.seed)
+        return loop.run(False), loop
+
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
+        """(k, state [N, Ds], out [M, T]) with k a float as in the reference (GNN.py:267, :280)."""
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        k, loop = self._run(g.device_graph(self.device), training, state0)
+        return k, loop.state(), loop.output()
+
+
+class GNNedgeBased(GNNnodeBased):
+    """GNN for edge-based problems.  The per-arc readout (reference GNN.py:289-302) is not on the device yet."""
+
+    def Loop(self, g, *, training: bool = False, state0=None):
+        raise NotImplementedError('GNNedgeBased: the arc-state readout (reference GNN.py:289-302) is not implemented on the MI355X engine yet')
+
+
+class GNNgraphBased(GNNnodeBased):
+    """GNN for graph-based problems: node-based Loop followed by the NodeGraph readout (reference GNN.py:318-333)."""
+
+    @staticmethod
+    def get_filtered_tensor(g: GraphTensor, inp):
+        return np.asarray(inp, dtype=np.float32)      # targets are per graph: never filtered (reference GNN.py:313-315)
+
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
+        if g.NodeGraph is None: raise ValueError('WRONG GNN. NodeGraph is None: GNN is graph-based, while problem is non graph-based.')
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        if not g.loop_mask().all():
+            # the reference multiplies NodeGraph [N, G] with the masked node outputs [M, T]: a shape error unless M == N
+            raise ValueError('graph-based GNN needs set_mask and output_mask all True (NodeGraph rows must match node outputs)')
+        k, loop = self._run(g.device_graph(self.device), training, state0)
+        return k, loop.state(), loop.readout(*g.nodegraph_csr())

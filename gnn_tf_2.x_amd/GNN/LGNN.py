@@ -1,0 +1,157 @@
+"""Layered GNN with the reference's public surface (``GNN/LGNN.py``): a stack of GNNs in which layer i+1 sees the
+ORIGINAL node labels widened by layer i's state and/or output (reference LGNN.py:227-290).
+
+The whole stack stays on the MI355X: each layer is one ``gnn_loop_run``; the relabelling between layers
+(``update_graph``: concat + scatter through the mask) is ``gnn_graph_update_labels`` on device-resident graphs that share
+one CSR.
+"""
+from __future__ import annotations
+
+from typing import Optional, Union
+
+import numpy as np
+
+from GNN.GNN import GNNnodeBased, GNNgraphBased, GNNedgeBased
+from GNN.GNN_BaseClass import BaseClass
+from GNN.graph_class import GraphObject, GraphTensor
+
+
+class LGNN(BaseClass):
+    def __init__(self, gnns: list, get_state: bool, get_output: bool, optimizer, loss_function, loss_arguments: Optional[dict],
+                 addressed_problem: str, extra_metrics: Optional[dict] = None, extra_metrics_arguments: Optional[dict[str, dict]] = None,
+                 path_writer: str = 'writer/', namespace: str = 'LGNN') -> None:
+        kinds = {type(i) for i in gnns}
+        if len(kinds) != 1: raise TypeError('parameter <gnn> must contain gnns of the same type')
+        super().__init__(optimizer, loss_function, loss_arguments, addressed_problem, extra_metrics, extra_metrics_arguments,
+                         path_writer, namespace)
+        self.get_state = get_state
+        self.get_output = get_output
+        self.gnns = gnns
+        self.LAYERS = len(gnns)
+        self.GNNS_TYPE = kinds.pop()
+        self.namespace = [f'{namespace} - GNN{i}' for i in range(self.LAYERS)]
+        self.training_mode = None
+        for gnn, name in zip(self.gnns, self.namespace):
+            gnn.namespace = [name]
+            gnn.path_writer = f'{self.path_writer}{name}/'
+
+    def copy(self, *, path_writer: str = '', namespace: str = '', copy_weights: bool = True) -> 'LGNN':
+        optimizer = self.optimizer
+        if hasattr(optimizer, 'get_config'):
+            optimizer = optimizer.__class__(**optimizer.get_config())
+        return self.__class__(gnns=[i.copy(copy_weights=copy_weights) for i in self.gnns], get_state=self.get_state,
+                              get_output=self.get_output, optimizer=optimizer, loss_function=self.loss_function,
+                              loss_arguments=self.loss_args, addressed_problem=self.addressed_problem,
+                              extra_metrics=self.extra_metrics, extra_metrics_arguments=self.mt_args,
+                              path_writer=path_writer or self.path_writer + '_copied/', namespace=namespace or 'LGNN')
+
+    def save(self, path: str):
+        import json, os
+        if path[-1] != '/': path += '/'
+        for i, gnn in enumerate(self.gnns): gnn.save(f'{path}GNN{i}/')
+        os.makedirs(path, exist_ok=True)
+        with open(f'{path}config.json', 'w') as f:
+            json.dump({'get_state': self.get_state, 'get_output': self.get_output, 'loss_arguments': self.loss_args,
+                       'addressed_problem': self.addressed_problem}, f)
+
+    # ---- weights ------------------------------------------------------------------------------------------------------
+    def get_dense_layers(self):
+        return [layer for gnn in self.gnns for layer in gnn.get_dense_layers()]
+
+    def trainable_variables(self):
+        return [g.net_state.trainable_variables for g in self.gnns], [g.net_output.trainable_variables for g in self.gnns]
+
+    def get_weights(self):
+        return [g.net_state.get_weights() for g in self.gnns], [g.net_output.get_weights() for g in self.gnns]
+
+    def set_weights(self, weights_state, weights_output) -> None:
+        assert len(weights_state) == len(weights_output) == self.LAYERS
+        for gnn, ws, wo in zip(self.gnns, weights_state, weights_output):
+            gnn.net_state.set_weights(ws)
+            gnn.net_output.set_weights(wo)
+
+    # ---- inference ------------------------------------------------------------------------------------------------------
+    def __call__(self, g: Union[GraphObject, GraphTensor]):
+        return self.Loop(g, training=False)[-1][-1]
+
+    def predict(self, g: Union[GraphObject, GraphTensor], idx: Union[int, list[int], range, str] = -1):
+        """Output(s) of the chosen layer(s) (reference LGNN.py:172-198)."""
+        layers = range(self.LAYERS)
+        if isinstance(idx, int):
+            assert idx in layers
+        elif isinstance(idx, (list, range)):
+            assert all(i in layers for i in idx)
+            idx = sorted(idx)
+        elif idx == 'all':
+            idx = layers
+        else:
+            raise ValueError('param <idx> must be 1.int; 2.list of ordered ints in range(self.LAYERS); 3. str "all"')
+        out = self.Loop(g, training=False)[-1]
+        return out[idx] if isinstance(idx, int) else [out[i] for i in idx]
+
+    def evaluate_single_graph(self, g: Union[GraphObject, GraphTensor], training: bool) -> tuple:
+        """Parallel mode: mean of the per-layer losses; residual (training only): loss of the mean output
+        (reference LGNN.py:201-224)."""
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        targs = self.GNNS_TYPE.get_filtered_tensor(g, g.targets)
+        loss_weights = self.GNNS_TYPE.get_filtered_tensor(g, g.sample_weights)
+        it, _, out = self.Loop(g, training=training)
+        if training and self.training_mode == 'residual':
+            loss = self.loss_function(targs, np.mean(out, axis=0), **self.loss_args) * loss_weights
+        else:
+            loss = np.mean([self.loss_function(targs, o, **self.loss_args) * loss_weights for o in out], axis=0)
+        return it, np.sum(loss), targs, out[-1]
+
+    def update_graph(self, g: GraphTensor, state, output) -> GraphTensor:
+        """Host form of the relabelling (reference LGNN.py:227-260); Loop uses the device form instead."""
+        if self.GNNS_TYPE == GNNedgeBased:
+            raise NotImplementedError('edge-based LGNN relabelling (reference LGNN.py:253-254) is not implemented yet')
+        g = g.copy()
+        extra = []
+        if self.get_state: extra.append(np.asarray(state, dtype=np.float32))
+        if self.get_output:
+            mask = g.loop_mask()
+            scattered = np.zeros((len(mask), output.shape[1]), dtype=np.float32)
+            scattered[np.nonzero(mask)[0]] = output
+            extra.append(scattered)
+        g.nodes = np.concatenate([g.nodes] + extra, axis=1)
+        return g
+
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
+        """(K list, last state, outs list) as reference LGNN.py:263-290.  ``state0``: optional list of injected initial
+        states, one per layer."""
+        if self.GNNS_TYPE == GNNedgeBased:
+            raise NotImplementedError('edge-based LGNN is not implemented on the MI355X engine yet')
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        graph_based = self.GNNS_TYPE == GNNgraphBased
+        if graph_based:
+            if g.NodeGraph is None: raise ValueError('WRONG GNN. NodeGraph is None: GNN is graph-based, while problem is non graph-based.')
+            if not g.loop_mask().all(): raise ValueError('graph-based GNN needs set_mask and output_mask all True')
+        state0 = state0 or [None] * self.LAYERS
+        base = g.device_graph(self.gnns[0].device)
+        current = base
+        derived = g.__dict__.setdefault('_lgnn_graphs', {})
+        K, outs = [], []
+        loop = None
+        for idx, gnn in enumerate(self.gnns):
+            k, loop = gnn._run(current, training, state0[idx])
+            K.append(k)
+            last = idx == self.LAYERS - 1
+            outs.append(loop.readout(*g.nodegraph_csr()) if graph_based else loop.output())
+            if not last:
+                # relabel from the ORIGINAL graph (reference LGNN.py:287): [nodes | state? | scattered output?]
+                extra = self.get_state * loop.Ds + self.get_output * loop.T
+                nxt = derived.get(extra)
+                if nxt is None:
+                    nxt = derived[extra] = base.derive(extra)
+                nxt.update_labels(base, loop, self.get_state, self.get_output)
+                current = nxt
+        return K, loop.state(), outs
+
+    # ---- training ---------------------------------------------------------------------------------------------------------
+    def train(self, gTr, epochs: int, gVa=None, update_freq: int = 10, max_fails: int = 10, observed_metric: str = 'Loss',
+              policy='min', *, mean: bool = True, training_mode: str = 'parallel', verbose: int = 3) -> None:
+        assert training_mode in ['parallel', 'serial', 'residual']
+        if (self.training_mode is not None) and (self.training_mode != training_mode): raise ValueError
+        self.training_mode = training_mode
+        super().train(gTr, epochs, gVa, update_freq, max_fails, observed_metric, policy, mean=mean, verbose=verbose)

@@ -1,0 +1,304 @@
+"""ctypes binding of include/gnn_hip.h (libgnn_hip.so).  This is the only door from Python into the product.
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgnn_hip.so')
+
+ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 'sigmoid': 5, 'softmax': 6}
+
+EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create',
+           'gnn_graph_derive', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
+           'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
+           'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout',
+           'gnn_loop_set_impl', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
+           'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy']
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libgnn_hip.so once.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                              f'or `make -C gnn_tf_2.x_amd/csrc`')
+        _lib = C.CDLL(LIB_PATH)
+        _lib.gnn_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if name != 'gnn_last_error':
+                getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _check(rc: int):
+    if rc == 0:
+        return
+    msg = lib().gnn_last_error().decode(errors='replace')
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -5:
+        raise NotImplementedError(msg)
+    raise EngineError(f'[gnn_status {rc}] {msg}')
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f'expected shape {tuple(shape)}, got {a.shape}')
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().gnn_device_count(C.byref(n)))
+    return n.value
+
+
+def require_device(device: int = 0) -> None:
+    n = device_count()
+    if n <= device:
+        raise EngineError(f'no HIP device {device} visible ({n} found): this engine only runs on MI355X (gfx950)')
+
+
+def shard_range(n_nodes: int, rank: int, world: int) -> tuple[int, int]:
+    b, n = C.c_int64(0), C.c_int64(0)
+    _check(lib().gnn_shard_range(C.c_int64(n_nodes), C.c_int(rank), C.c_int(world), C.byref(b), C.byref(n)))
+    return b.value, n.value
+
+
+class Graph:
+    """Device-resident graph (gnn_graph).  CSR "by destination" as produced by graph_class.GraphTensor."""
+
+    def __init__(self, n_nodes, indptr, adj_src, adj_w, arc_w, arc_labels, nodes, mask, row_begin=0, device=0, _handle=None):
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+            return
+        require_device(device)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        adj_src = np.ascontiguousarray(adj_src, dtype=np.int32)
+        adj_w, arc_w = _f32(adj_w), _f32(arc_w)
+        arc_labels, nodes = _f32(arc_labels), _f32(nodes)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        n_rows, n_arcs = len(indptr) - 1, len(adj_src)
+        if arc_labels.ndim != 2 or arc_labels.shape[0] != n_arcs or nodes.ndim != 2 or nodes.shape[0] != n_nodes:
+            raise ValueError('arc_labels must be [n_arcs, AL] and nodes [n_nodes, NL]')
+        if len(adj_w) != n_arcs or len(arc_w) != n_arcs or len(mask) != n_rows:
+            raise ValueError('inconsistent array lengths')
+        _check(lib().gnn_graph_create(C.c_int64(n_nodes), C.c_int64(row_begin), C.c_int64(n_rows), C.c_int64(n_arcs),
+                                      _ip(indptr), _ip(adj_src), _fp(adj_w), _fp(arc_w), _fp(arc_labels),
+                                      C.c_int(arc_labels.shape[1]), _fp(nodes), C.c_int(nodes.shape[1]),
+                                      mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(device), C.byref(self._h)))
+
+    def dims(self):
+        n, r, e, m = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        nl, al = C.c_int(), C.c_int()
+        _check(lib().gnn_graph_dims(self._h, C.byref(n), C.byref(r), C.byref(e), C.byref(nl), C.byref(al), C.byref(m)))
+        return dict(n_nodes=n.value, n_rows=r.value, n_arcs=e.value, NL=nl.value, AL=al.value, n_masked=m.value)
+
+    def derive(self, extra: int) -> 'Graph':
+        h = C.c_void_p()
+        _check(lib().gnn_graph_derive(self._h, C.c_int(extra), C.byref(h)))
+        return Graph(None, None, None, None, None, None, None, None, _handle=h)
+
+    def update_labels(self, base: 'Graph', loop: 'Loop', get_state: bool, get_output: bool) -> None:
+        _check(lib().gnn_graph_update_labels(self._h, base._h, loop._h, C.c_int(bool(get_state)), C.c_int(bool(get_output))))
+
+    def nodes(self) -> np.ndarray:
+        d = self.dims()
+        out = np.empty((d['n_nodes'], d['NL']), dtype=np.float32)
+        _check(lib().gnn_graph_get_nodes(self._h, _fp(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().gnn_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mlp:
+    """Device-resident Sequential (gnn_mlp): Keras get_weights() list + activation names."""
+
+    def __init__(self, weights, activations, batch_normalization, bn_eps=1e-3, device=0):
+        require_device(device)
+        self._h = C.c_void_p()
+        self.n = len(activations)
+        self.activations = list(activations)
+        self.batch_normalization = bool(batch_normalization)
+        for a in activations:
+            if a not in ACT_CODES:
+                raise ValueError(f'unsupported activation {a!r}')
+        w, b, bn = self._pack(weights)
+        self.dims = np.array([w[0].shape[0]] + [x.shape[1] for x in w], dtype=np.int32)
+        acts = np.array([ACT_CODES[a] for a in activations], dtype=np.int32)
+        wp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in w])
+        bp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in b])
+        _check(lib().gnn_mlp_create(C.c_int(self.n), _ip(self.dims), _ip(acts), wp, bp, _fp(bn), C.c_float(bn_eps),
+                                    C.c_int(device), C.byref(self._h)))
+
+    def _pack(self, weights):
+        n = self.n
+        if len(weights) != 2 * n + (4 if self.batch_normalization else 0):
+            raise ValueError(f'expected {2 * n + (4 if self.batch_normalization else 0)} weight arrays, got {len(weights)}')
+        w = [_f32(weights[2 * l]) for l in range(n)]
+        b = [_f32(weights[2 * l + 1]) for l in range(n)]
+        for l in range(n):
+            if w[l].ndim != 2 or b[l].shape != (w[l].shape[1],) or (l and w[l].shape[0] != w[l - 1].shape[1]):
+                raise ValueError(f'layer {l}: inconsistent weight shapes')
+        bn = None
+        if self.batch_normalization:
+            bn = np.ascontiguousarray(np.concatenate([_f32(a).ravel() for a in weights[2 * n:]]))
+            if bn.size != 4 * w[-1].shape[1]:
+                raise ValueError('BatchNormalization arrays must each have the output width')
+        return w, b, bn
+
+    def set_weights(self, weights):
+        w, b, bn = self._pack(weights)
+        if [x.shape for x in w] != [(int(self.dims[l]), int(self.dims[l + 1])) for l in range(self.n)]:
+            raise ValueError('weight shapes differ from the ones this MLP was created with')
+        wp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in w])
+        bp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in b])
+        _check(lib().gnn_mlp_set_weights(self._h, wp, bp, _fp(bn)))
+
+    def forward(self, x):
+        x = _f32(x)
+        if x.ndim != 2 or x.shape[1] != self.dims[0]:
+            raise ValueError(f'expected [n, {self.dims[0]}] input')
+        y = np.empty((x.shape[0], int(self.dims[-1])), dtype=np.float32)
+        _check(lib().gnn_mlp_forward(self._h, C.c_int64(x.shape[0]), _fp(x), _fp(y)))
+        return y
+
+    def close(self):
+        if self._h:
+            lib().gnn_mlp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator (one process per GPU)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib().gnn_comm_create(buf, C.c_int(rank), C.c_int(world), C.c_int(device), C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(lib().gnn_comm_unique_id(buf))
+        return bytes(buf)
+
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(value)
+        _check(lib().gnn_comm_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._h:
+            lib().gnn_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+class Loop:
+    """One configured GNN.Loop on the device (gnn_loop)."""
+
+    def __init__(self, graph: Graph, net_state: Mlp, net_output: Mlp, state_dim: int, max_iter: int, threshold: float,
+                 comm: Comm | None = None):
+        self._h = C.c_void_p()
+        self._keep = (graph, net_state, net_output, comm)
+        self.graph = graph
+        d = graph.dims()
+        self.n_rows, self.n_masked = d['n_rows'], d['n_masked']
+        self.Ds = state_dim if state_dim else d['NL']
+        self.T = int(net_output.dims[-1])
+        self.state_dim = state_dim
+        _check(lib().gnn_loop_create(graph._h, net_state._h, net_output._h, C.c_int(state_dim), C.c_int(max_iter),
+                                     C.c_float(threshold), comm._h if comm else None, C.byref(self._h)))
+
+    def set_state0(self, state0=None, seed: int = 0):
+        if state0 is not None:
+            state0 = _f32(state0, (self.n_rows, self.Ds))
+        _check(lib().gnn_loop_set_state0(self._h, _fp(state0), C.c_uint64(seed)))
+
+    def set_impl(self, impl: int) -> int:
+        used = C.c_int(0)
+        _check(lib().gnn_loop_set_impl(self._h, C.c_int(impl), C.byref(used)))
+        return used.value
+
+    def set_profiling(self, on: bool):
+        _check(lib().gnn_loop_set_profiling(self._h, C.c_int(bool(on))))
+
+    def run(self, training: bool = False) -> float:
+        k = C.c_float(0)
+        _check(lib().gnn_loop_run(self._h, C.c_int(bool(training)), C.byref(k)))
+        return float(k.value)
+
+    def timing(self):
+        tot, avg, n = C.c_float(), C.c_float(), C.c_int()
+        _check(lib().gnn_loop_get_timing(self._h, C.byref(tot), C.byref(avg), C.byref(n)))
+        return dict(total_ms=tot.value, avg_iter_ms=avg.value, n_iter_timed=n.value)
+
+    def state(self) -> np.ndarray:
+        out = np.empty((self.n_rows, self.Ds), dtype=np.float32)
+        _check(lib().gnn_loop_get_state(self._h, _fp(out)))
+        return out
+
+    def output(self) -> np.ndarray:
+        out = np.empty((self.n_masked, self.T), dtype=np.float32)
+        m = C.c_int64(0)
+        _check(lib().gnn_loop_get_output(self._h, _fp(out), C.byref(m)))
+        return out
+
+    def readout(self, ng_indptr, ng_node, ng_w) -> np.ndarray:
+        ng_indptr = np.ascontiguousarray(ng_indptr, dtype=np.int32)
+        ng_node = np.ascontiguousarray(ng_node, dtype=np.int32)
+        ng_w = _f32(ng_w)
+        g = len(ng_indptr) - 1
+        out = np.empty((g, self.T), dtype=np.float32)
+        _check(lib().gnn_loop_readout(self._h, C.c_int(g), _ip(ng_indptr), _ip(ng_node), _fp(ng_w), _fp(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().gnn_loop_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

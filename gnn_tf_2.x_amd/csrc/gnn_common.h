@@ -1,0 +1,152 @@
+// Shared declarations of the gfx950 engine (host side + device helpers).  Not part of the public ABI (include/gnn_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "gnn_hip.h"
+
+int gnn_fail(int code, const char *fmt, ...);
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return gnn_fail(GNN_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define ARGCHK(cond, ...)                                     \
+    do {                                                      \
+        if (!(cond)) return gnn_fail(GNN_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// device math with a pinned evaluation order (mirrors oracle/gnn_oracle.c; the file is compiled with
+// -ffp-contract=off, so only the explicit fmaf() calls fuse)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gnn_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -87.33654022216797f) return 0.0f;
+    float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float y = __builtin_fmaf(p, z, r);
+    y = y + 1.0f;
+    int ni = (int)n;
+    int n1 = ni / 2, n2 = ni - n1;
+    float s1 = __uint_as_float((uint32_t)(n1 + 127) << 23), s2 = __uint_as_float((uint32_t)(n2 + 127) << 23);
+    return (y * s1) * s2;
+}
+
+__device__ __forceinline__ float gnn_act(float v, int act)
+{
+    switch (act) {
+    case GNN_ACT_RELU: return v > 0.0f ? v : 0.0f;
+    case GNN_ACT_SELU: {
+        float neg = 1.6732632423543772f * (gnn_expf(v) - 1.0f);
+        return 1.0507009873554805f * (v > 0.0f ? v : neg);
+    }
+    case GNN_ACT_ELU: return v > 0.0f ? v : (gnn_expf(v) - 1.0f);
+    case GNN_ACT_TANH: {
+        float a = __builtin_fabsf(v);
+        float t = gnn_expf(-2.0f * a);
+        float q = __fdiv_rn(1.0f - t, 1.0f + t);
+        return v < 0.0f ? -q : q;
+    }
+    case GNN_ACT_SIGMOID: return __fdiv_rn(1.0f, 1.0f + gnn_expf(-v));
+    default: return v;
+    }
+}
+
+// iteration gate: flags[k*P .. k*P+P) hold, per rank, "some owned node has not converged"; body k runs iff any is set
+__device__ __forceinline__ bool gnn_gate_open(const int *gate, int world)
+{
+    if (!gate) return true;
+    int any = 0;
+    for (int p = 0; p < world; ++p) any |= gate[p];
+    return any != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------------------------------
+struct gnn_graph_shared {
+    int refs = 1;
+    int32_t *indptr = nullptr, *adj_src = nullptr, *masked_rows = nullptr;
+    float *adj_w = nullptr, *arc_w = nullptr, *arc_labels = nullptr;
+    uint8_t *mask = nullptr;
+    int max_degree = 0;
+};
+
+struct gnn_graph {
+    int device = 0;
+    int64_t N = 0, row_begin = 0, n_rows = 0, E = 0, n_masked = 0;
+    int NL = 0, AL = 0;
+    gnn_graph_shared *sh = nullptr;
+    float *nodes = nullptr;   // [N, NL]
+    int base_NL = 0;          // derived graphs: label width of the base graph
+};
+
+struct gnn_mlp {
+    int device = 0;
+    int n_layers = 0;
+    std::vector<int> dims, acts;
+    std::vector<float *> W, b;          // device, Keras layout
+    float *bn_scale = nullptr, *bn_shift = nullptr;   // device, [dims.back()]
+    bool has_bn = false;
+    float eps = 1e-3f;
+    // fused-kernel weight image (see gnn_fused.hip), rebuilt by set_weights
+    float *packed = nullptr;
+    size_t packed_floats = 0;
+    uint64_t version = 0;
+};
+
+struct gnn_comm {
+    int rank = 0, world = 1, device = 0;
+    void *nccl = nullptr;       // ncclComm_t
+    hipStream_t stream = nullptr;
+    double *scratch = nullptr;  // device, for allreduce_max
+};
+
+struct gnn_loop {
+    gnn_graph *g = nullptr;
+    gnn_mlp *st = nullptr, *ou = nullptr;
+    gnn_comm *comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+    int D = 0, Ds = 0, NLc = 0, in_s = 0, wf = 0, T = 0, max_iter = 0;
+    float thr = 0.f;
+    int64_t shard_rows = 0, N_pad = 0;
+    hipStream_t stream = nullptr;
+    float *state[2] = {nullptr, nullptr};   // [N_pad, Ds] full replicas, ping-pong
+    float *state_init = nullptr;            // [n_rows, Ds] initial state of the owned rows (D > 0)
+    float *inp = nullptr;                   // unfused: materialised concat [n_rows, in_s]
+    float *inv = nullptr;                   // fused: loop-invariant label block [n_rows, inv_w]
+    float *tmp[2] = {nullptr, nullptr};     // unfused: layer activations
+    float *feats = nullptr, *out = nullptr, *otmp[2] = {nullptr, nullptr};
+    int *flags = nullptr;                   // [(max_iter+1) * world]
+    int *kfinal_dev = nullptr, *kfinal_host = nullptr;
+    int kfinal = -1;
+    bool have_state0 = false, ran = false;
+    int impl_req = 1, impl_used = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t ev_total[2] = {nullptr, nullptr};
+    float total_ms = 0.f, avg_iter_ms = 0.f;
+    int n_iter_timed = 0;
+};
+
+// gnn_fused.hip
+bool gnn_fused_supported(const gnn_loop *l);
+int gnn_fused_prepare(gnn_loop *l);
+int gnn_fused_pack(gnn_mlp *m);
+int gnn_fused_iteration(gnn_loop *l, int k);
+void gnn_fused_release(gnn_mlp *m);

@@ -1,0 +1,1013 @@
+// gfx950 engine for the GNN fixed-point loop: handles, the per-op ("unfused") kernels and the loop driver.
+//
+// Every kernel here evaluates floating point in the order pinned by oracle/gnn_oracle.c (sequential fmaf chains,
+// unfused BatchNormalization and norms), so results are bit-identical to that restatement.  The fused fast path is in
+// gnn_fused.hip; this file is its fallback for shapes it does not cover and the GPU-side cross-check of it.
+//
+// Reference call sites replaced (paths relative to the reference root):
+//   k_spmm        tf.sparse.sparse_dense_matmul   GNN/GNN.py:234, :259, :263
+//   k_dense       Keras Dense + activation        GNN/MLP.py:62 (built), GNN/GNN.py:240, :279 (called)
+//   k_softmax_bn  softmax activation + BatchNormalization (MLP.py:63)
+//   k_check       condition()                     GNN/GNN.py:202-220
+//   k_feats       apply_filters()                 GNN/GNN.py:245-248
+//   k_readout     tf.matmul(nodegraph, out, transpose_a=True)   GNN/GNN.py:331-332, GNN/LGNN.py:278
+//   k_relabel     LGNN.update_graph               GNN/LGNN.py:227-260
+#include <dlfcn.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "gnn_common.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+int gnn_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *gnn_last_error(void) { return g_err; }
+extern "C" int gnn_version(void) { return 1; }
+
+extern "C" int gnn_device_count(int *count)
+{
+    ARGCHK(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return GNN_OK;
+}
+
+extern "C" int gnn_device_synchronize(int device)
+{
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return GNN_OK;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
+    return GNN_OK;
+}
+
+template <typename T>
+static int dev_upload(T **p, const T *host, size_t count)
+{
+    int rc = dev_alloc(p, count);
+    if (rc) return rc;
+    if (count) HIPCHK(hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return GNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------------------------
+
+// out[r, :] = sum over the stored entries e of row r, in order, of w[e] * X[src(e), :]     (fmaf chain)
+// lpr lanes (power of two <= 64) cooperate on a row, each owning VEC consecutive columns per chunk.
+template <int VEC, bool INDEXED>
+__global__ void __launch_bounds__(256) k_spmm(int64_t n_rows, const int32_t *__restrict__ indptr,
+                                              const int32_t *__restrict__ idx, const float *__restrict__ w,
+                                              const float *__restrict__ X, int width, int64_t ldx,
+                                              float *__restrict__ out, int64_t ldo, int lpr, const int *gate, int world)
+{
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows_per_pass = ((int64_t)gridDim.x * blockDim.x) / lpr;
+    const int lane = (int)(gtid % lpr);
+    for (int64_t row = gtid / lpr; row < n_rows; row += rows_per_pass) {
+        const int beg = indptr[row], end = indptr[row + 1];
+        for (int c0 = lane * VEC; c0 < width; c0 += lpr * VEC) {
+            float acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+            int e = beg;
+            for (; e + 4 <= end; e += 4) {
+                float we[4];
+                float xv[4][VEC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    we[u] = w[e + u];
+                    const int64_t s = INDEXED ? (int64_t)idx[e + u] : (int64_t)(e + u);
+                    const float *xp = X + s * ldx + c0;
+                    if constexpr (VEC == 4) {
+                        const float4 t = *reinterpret_cast<const float4 *>(xp);
+                        xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                    } else {
+                        xv[u][0] = xp[0];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we[u], xv[u][v], acc[v]);
+            }
+            for (; e < end; ++e) {
+                const float we = w[e];
+                const int64_t s = INDEXED ? (int64_t)idx[e] : (int64_t)e;
+                const float *xp = X + s * ldx + c0;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we, xp[v], acc[v]);
+            }
+            float *op = out + row * ldo + c0;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) op[v] = acc[v];
+        }
+    }
+}
+
+// Y[i, j] = epilogue( sum_k fmaf(X[i,k], W[k,j]) + b[j] );  R rows per block staged in LDS, one thread per column.
+template <int R>
+__global__ void __launch_bounds__(256) k_dense(int64_t n, int n_in, int n_in_pad, int n_out, const float *__restrict__ X,
+                                               int64_t ldx, const float *__restrict__ W, const float *__restrict__ b,
+                                               int act, const float *__restrict__ bn_scale,
+                                               const float *__restrict__ bn_shift, float *__restrict__ Y, int64_t ldy,
+                                               const int *gate, int world)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t i0 = (int64_t)blockIdx.x * R;
+    for (int t = threadIdx.x; t < R * n_in_pad; t += blockDim.x) {
+        const int r = t / n_in_pad, k = t - r * n_in_pad;
+        xs[t] = (k < n_in && i0 + r < n) ? X[(i0 + r) * ldx + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_out; j += blockDim.x) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+        int k = 0;
+        for (; k + 4 <= n_in; k += 4) {
+            const float w0 = W[(size_t)(k + 0) * n_out + j], w1 = W[(size_t)(k + 1) * n_out + j];
+            const float w2 = W[(size_t)(k + 2) * n_out + j], w3 = W[(size_t)(k + 3) * n_out + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 x = *reinterpret_cast<const float4 *>(&xs[r * n_in_pad + k]);
+                acc[r] = __builtin_fmaf(x.x, w0, acc[r]);
+                acc[r] = __builtin_fmaf(x.y, w1, acc[r]);
+                acc[r] = __builtin_fmaf(x.z, w2, acc[r]);
+                acc[r] = __builtin_fmaf(x.w, w3, acc[r]);
+            }
+        }
+        for (; k < n_in; ++k) {
+            const float wk = W[(size_t)k * n_out + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(xs[r * n_in_pad + k], wk, acc[r]);
+        }
+        const float bj = b[j];
+        const float sc = bn_scale ? bn_scale[j] : 1.0f, sh = bn_shift ? bn_shift[j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (i0 + r >= n) break;
+            float v = acc[r] + bj;
+            if (act != GNN_ACT_SOFTMAX) {
+                v = gnn_act(v, act);
+                if (bn_scale) { float t = v * sc; v = t + sh; }
+            }
+            Y[(i0 + r) * ldy + j] = v;
+        }
+    }
+}
+
+// in-place row softmax (+ trailing BatchNormalization), one thread per row, sequential in j like the oracle
+__global__ void k_softmax_bn(int64_t n, int n_out, float *Y, int64_t ldy, const float *bn_scale, const float *bn_shift,
+                             const int *gate, int world)
+{
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float *y = Y + i * ldy;
+    float m = y[0];
+    for (int j = 1; j < n_out; ++j) m = y[j] > m ? y[j] : m;
+    float s = 0.0f;
+    for (int j = 0; j < n_out; ++j) { const float e = gnn_expf(y[j] - m); y[j] = e; s = s + e; }
+    for (int j = 0; j < n_out; ++j) {
+        float v = __fdiv_rn(y[j], s);
+        if (bn_scale) { float t = v * bn_scale[j]; v = t + bn_shift[j]; }
+        y[j] = v;
+    }
+}
+
+// condition(): per owned node sqrt(sum (s-so)^2) > thr * sqrt(sum so^2); OR into *flag_out.  so == nullptr: ones.
+__global__ void k_check(int64_t n_rows, int d, const float *__restrict__ s, const float *__restrict__ so, float thr,
+                        int *flag_out, const int *gate, int world)
+{
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int f = 0;
+    if (i < n_rows) {
+        float dist = 0.0f, nrm = 0.0f;
+        for (int c = 0; c < d; ++c) {
+            const float o = so ? so[i * d + c] : 1.0f;
+            const float df = s[i * d + c] - o;
+            const float dd = df * df;
+            dist = dist + dd;
+            const float oo = o * o;
+            nrm = nrm + oo;
+        }
+        const float lhs = __fsqrt_rn(dist);
+        const float rn = __fsqrt_rn(nrm);
+        const float rhs = thr * rn;
+        f = lhs > rhs;
+    }
+    if (__any(f) && (threadIdx.x & 63) == 0) atomicOr(flag_out, 1);
+}
+
+// k_final = number of executed bodies = first k whose gate is closed (or max_iter)
+__global__ void k_finalize(const int *flags, int world, int max_iter, int *kfinal)
+{
+    if (threadIdx.x | blockIdx.x) return;
+    int k = 0;
+    while (k < max_iter && gnn_gate_open(flags + (size_t)k * world, world)) ++k;
+    *kfinal = k;
+}
+
+// apply_filters(): feats[m] = [state_final[row_m] | nodes[row_m] (iff D > 0)]
+__global__ void k_feats(int64_t n_masked, const int32_t *__restrict__ masked_rows, const float *s0, const float *s1,
+                        const int *kfinal, int Ds, const float *__restrict__ nodes_own, int NL, int NLc,
+                        float *__restrict__ feats)
+{
+    const int wf = Ds + NLc;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_masked * wf) return;
+    const float *state = ((*kfinal) & 1) ? s1 : s0;
+    const int64_t m = t / wf;
+    const int c = (int)(t - m * wf);
+    const int64_t row = masked_rows[m];
+    feats[t] = c < Ds ? state[row * Ds + c] : nodes_own[row * NL + (c - Ds)];
+}
+
+// graph readout: out_graph[g, t] = sum over the stored (node, w) of graph g, ascending node, fmaf(w, out_nodes[node, t])
+__global__ void k_readout(int G, int T, const int32_t *__restrict__ indptr, const int32_t *__restrict__ node,
+                          const float *__restrict__ w, const float *__restrict__ out_nodes, float *__restrict__ out_graph)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= G * T) return;
+    const int g = t / T, c = t - g * T;
+    float acc = 0.0f;
+    for (int e = indptr[g]; e < indptr[g + 1]; ++e) acc = __builtin_fmaf(w[e], out_nodes[(int64_t)node[e] * T + c], acc);
+    out_graph[t] = acc;
+}
+
+// LGNN.update_graph: dst[i] = [base[i, :NLb] | state[i] (if get_state) | mask[i] ? out[pos(i)] : 0 (if get_output)]
+__global__ void k_relabel(int64_t N, int NLb, const float *__restrict__ base_nodes, int Ds, const float *s0,
+                          const float *s1, const int *kfinal, int get_state, int T, const float *__restrict__ out,
+                          const uint8_t *__restrict__ mask, const int32_t *__restrict__ mask_pos, int get_output,
+                          float *__restrict__ dst, int NLd)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * NLd) return;
+    const int64_t i = t / NLd;
+    int c = (int)(t - i * NLd);
+    float v;
+    if (c < NLb) {
+        v = base_nodes[i * NLb + c];
+    } else {
+        c -= NLb;
+        if (get_state && c < Ds) {
+            const float *state = ((*kfinal) & 1) ? s1 : s0;
+            v = state[i * Ds + c];
+        } else {
+            if (get_state) c -= Ds;
+            v = mask[i] ? out[(int64_t)mask_pos[i] * T + c] : 0.0f;
+        }
+    }
+    dst[t] = v;
+}
+
+// own RNG for the initial state when none is injected (tf.random.normal(stddev=0.1), GNN.py:262, cannot be matched)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void k_randn(int64_t count, int64_t offset, uint64_t seed, float stddev, float *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)(t + offset)));
+    const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777217.0f);
+    const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
+    out[t] = stddev * sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__global__ void k_fill(int64_t count, float v, float *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) out[t] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------------------
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+static int launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const int32_t *idx, const float *w,
+                       const float *X, int width, int64_t ldx, float *out, int64_t ldo, const int *gate, int world)
+{
+    if (n_rows == 0 || width == 0) return GNN_OK;
+    const bool vec4 = (width % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)X & 15) == 0);
+    const int vec = vec4 ? 4 : 1;
+    int lpr = 1;
+    while (lpr * vec < width && lpr < 64) lpr <<= 1;
+    const int64_t threads = n_rows * lpr;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv(threads, 256), 256 * 32);
+    const bool indexed = idx != nullptr;
+    if (vec4 && indexed) hipLaunchKernelGGL((k_spmm<4, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
+    else if (vec4) hipLaunchKernelGGL((k_spmm<4, false>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
+    else if (indexed) hipLaunchKernelGGL((k_spmm<1, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
+    else hipLaunchKernelGGL((k_spmm<1, false>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
+// Sequential forward on device buffers: X[n, dims[0]] (ldx) -> Y[n, dims.back()] (ldy); t0/t1: [n, max hidden width]
+static int launch_mlp(hipStream_t st, const gnn_mlp *m, int64_t n, const float *X, int64_t ldx, float *Y, int64_t ldy,
+                      float *t0, float *t1, const int *gate, int world)
+{
+    if (n == 0) return GNN_OK;
+    const float *in = X;
+    int64_t ldin = ldx;
+    constexpr int R = 8;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const bool last = l == m->n_layers - 1;
+        float *out = last ? Y : ((l & 1) ? t1 : t0);
+        const int64_t ldo = last ? ldy : m->dims[l + 1];
+        const int n_in = m->dims[l], n_out = m->dims[l + 1], act = m->acts[l];
+        const int n_in_pad = (n_in + 3) & ~3;
+        const size_t lds = sizeof(float) * R * n_in_pad;
+        if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer input width %d too large", n_in);
+        const int threads = std::min(256, ((n_out + 63) / 64) * 64);
+        const float *sc = (last && m->has_bn) ? m->bn_scale : nullptr, *sh = (last && m->has_bn) ? m->bn_shift : nullptr;
+        hipLaunchKernelGGL((k_dense<R>), cdiv(n, R), threads, lds, st, n, n_in, n_in_pad, n_out, in, ldin, m->W[l], m->b[l],
+                           act, sc, sh, out, ldo, gate, world);
+        HIPCHK(hipGetLastError());
+        if (act == GNN_ACT_SOFTMAX) {
+            hipLaunchKernelGGL(k_softmax_bn, cdiv(n, 256), 256, 0, st, n, n_out, out, ldo, sc, sh, gate, world);
+            HIPCHK(hipGetLastError());
+        }
+        in = out;
+        ldin = ldo;
+    }
+    return GNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// graph
+// ---------------------------------------------------------------------------------------------------------------------
+static void graph_release_shared(gnn_graph_shared *sh)
+{
+    if (!sh || --sh->refs > 0) return;
+    (void)hipFree(sh->indptr); (void)hipFree(sh->adj_src); (void)hipFree(sh->masked_rows);
+    (void)hipFree(sh->adj_w); (void)hipFree(sh->arc_w); (void)hipFree(sh->arc_labels); (void)hipFree(sh->mask);
+    delete sh;
+}
+
+extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_rows, int64_t n_arcs,
+                                const int32_t *indptr, const int32_t *adj_src, const float *adj_w, const float *arc_w,
+                                const float *arc_labels, int dim_arc_label, const float *nodes, int dim_node_label,
+                                const uint8_t *mask, int device, gnn_graph **out)
+{
+    ARGCHK(out, "out is NULL");
+    *out = nullptr;
+    ARGCHK(n_nodes > 0 && n_nodes < (int64_t)1 << 31, "n_nodes=%lld out of range", (long long)n_nodes);
+    ARGCHK(row_begin >= 0 && n_rows >= 0 && row_begin + n_rows <= n_nodes, "owned rows [%lld,+%lld) outside [0,%lld)",
+           (long long)row_begin, (long long)n_rows, (long long)n_nodes);
+    ARGCHK(n_arcs >= 0 && n_arcs < (int64_t)1 << 31, "n_arcs=%lld out of range", (long long)n_arcs);
+    ARGCHK(dim_node_label > 0 && dim_arc_label >= 0, "label dims must be NL>0, AL>=0");
+    ARGCHK(indptr && nodes && mask, "indptr/nodes/mask are required");
+    ARGCHK(n_arcs == 0 || (adj_src && adj_w && arc_w && (arc_labels || dim_arc_label == 0)), "arc arrays are required");
+    ARGCHK(indptr[0] == 0 && indptr[n_rows] == n_arcs, "indptr[0]=%d, indptr[n_rows]=%d, n_arcs=%lld", indptr[0],
+           indptr[n_rows], (long long)n_arcs);
+    int maxdeg = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int d = indptr[r + 1] - indptr[r];
+        ARGCHK(d >= 0, "indptr not monotone at row %lld", (long long)r);
+        maxdeg = std::max(maxdeg, d);
+    }
+    for (int64_t e = 0; e < n_arcs; ++e)
+        ARGCHK(adj_src[e] >= 0 && adj_src[e] < n_nodes, "adj_src[%lld]=%d outside [0,%lld)", (long long)e, adj_src[e], (long long)n_nodes);
+
+    HIPCHK(hipSetDevice(device));
+    gnn_graph *g = new gnn_graph();
+    g->device = device; g->N = n_nodes; g->row_begin = row_begin; g->n_rows = n_rows; g->E = n_arcs;
+    g->NL = dim_node_label; g->AL = dim_arc_label; g->base_NL = dim_node_label;
+    g->sh = new gnn_graph_shared();
+    g->sh->max_degree = maxdeg;
+    // masked_rows holds [n_masked] owned-row indices with mask set, followed by [n_rows] exclusive positions
+    std::vector<int32_t> rows, pos((size_t)n_rows);
+    for (int64_t r = 0; r < n_rows; ++r) { pos[r] = (int32_t)rows.size(); if (mask[r]) rows.push_back((int32_t)r); }
+    g->n_masked = (int64_t)rows.size();
+    std::vector<int32_t> both(rows);
+    both.insert(both.end(), pos.begin(), pos.end());
+    int rc = 0;
+    if ((rc = dev_upload(&g->sh->indptr, indptr, (size_t)n_rows + 1)) || (rc = dev_upload(&g->sh->adj_src, adj_src, (size_t)n_arcs)) ||
+        (rc = dev_upload(&g->sh->adj_w, adj_w, (size_t)n_arcs)) || (rc = dev_upload(&g->sh->arc_w, arc_w, (size_t)n_arcs)) ||
+        (rc = dev_upload(&g->sh->arc_labels, arc_labels, (size_t)n_arcs * dim_arc_label)) ||
+        (rc = dev_upload(&g->sh->mask, mask, (size_t)n_rows)) || (rc = dev_upload(&g->sh->masked_rows, both.data(), both.size())) ||
+        (rc = dev_upload(&g->nodes, nodes, (size_t)n_nodes * dim_node_label))) {
+        gnn_graph_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return GNN_OK;
+}
+
+static inline const int32_t *graph_mask_pos(const gnn_graph *g) { return g->sh->masked_rows + g->n_masked; }
+
+extern "C" int gnn_graph_derive(const gnn_graph *base, int extra, gnn_graph **out)
+{
+    ARGCHK(base && out && extra >= 0, "bad arguments");
+    HIPCHK(hipSetDevice(base->device));
+    gnn_graph *g = new gnn_graph(*base);
+    g->sh->refs++;
+    g->NL = base->base_NL + extra;
+    g->nodes = nullptr;
+    int rc = dev_alloc(&g->nodes, (size_t)g->N * g->NL);
+    if (rc) { gnn_graph_destroy(g); return rc; }
+    HIPCHK(hipMemset(g->nodes, 0, (size_t)g->N * g->NL * sizeof(float)));
+    *out = g;
+    return GNN_OK;
+}
+
+extern "C" int gnn_graph_get_nodes(const gnn_graph *g, float *nodes_out)
+{
+    ARGCHK(g && nodes_out, "bad arguments");
+    HIPCHK(hipSetDevice(g->device));
+    HIPCHK(hipMemcpy(nodes_out, g->nodes, (size_t)g->N * g->NL * sizeof(float), hipMemcpyDeviceToHost));
+    return GNN_OK;
+}
+
+extern "C" int gnn_graph_dims(const gnn_graph *g, int64_t *n_nodes, int64_t *n_rows, int64_t *n_arcs, int *nl, int *al,
+                              int64_t *n_masked)
+{
+    ARGCHK(g, "graph is NULL");
+    if (n_nodes) *n_nodes = g->N;
+    if (n_rows) *n_rows = g->n_rows;
+    if (n_arcs) *n_arcs = g->E;
+    if (nl) *nl = g->NL;
+    if (al) *al = g->AL;
+    if (n_masked) *n_masked = g->n_masked;
+    return GNN_OK;
+}
+
+extern "C" int gnn_graph_destroy(gnn_graph *g)
+{
+    if (!g) return GNN_OK;
+    (void)hipSetDevice(g->device);
+    (void)hipFree(g->nodes);
+    graph_release_shared(g->sh);
+    delete g;
+    return GNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MLP
+// ---------------------------------------------------------------------------------------------------------------------
+static int mlp_upload(gnn_mlp *m, const float *const *W, const float *const *b, const float *bn)
+{
+    for (int l = 0; l < m->n_layers; ++l) {
+        ARGCHK(W[l] && b[l], "W[%d]/b[%d] is NULL", l, l);
+        HIPCHK(hipMemcpy(m->W[l], W[l], sizeof(float) * (size_t)m->dims[l] * m->dims[l + 1], hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(m->b[l], b[l], sizeof(float) * (size_t)m->dims[l + 1], hipMemcpyHostToDevice));
+    }
+    if (m->has_bn) {
+        ARGCHK(bn, "this MLP ends with BatchNormalization: bn is required");
+        const int f = m->dims.back();
+        std::vector<float> sc(f), sh(f);
+        for (int j = 0; j < f; ++j) {   // same expression order as oracle/gnn_oracle.c:orc_batchnorm
+            const float g = bn[j], be = bn[f + j], mu = bn[2 * f + j], var = bn[3 * f + j];
+            sc[j] = (1.0f / sqrtf(var + m->eps)) * g;
+            const float t = mu * sc[j];
+            sh[j] = be - t;
+        }
+        HIPCHK(hipMemcpy(m->bn_scale, sc.data(), sizeof(float) * f, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(m->bn_shift, sh.data(), sizeof(float) * f, hipMemcpyHostToDevice));
+    }
+    m->version++;
+    return gnn_fused_pack(m);
+}
+
+extern "C" int gnn_mlp_create(int n_layers, const int32_t *dims, const int32_t *acts, const float *const *W,
+                              const float *const *b, const float *bn, float bn_eps, int device, gnn_mlp **out)
+{
+    ARGCHK(out, "out is NULL");
+    *out = nullptr;
+    ARGCHK(n_layers >= 1 && n_layers <= 16 && dims && acts && W && b, "bad MLP description");
+    for (int l = 0; l <= n_layers; ++l) ARGCHK(dims[l] > 0 && dims[l] <= 8192, "dims[%d]=%d", l, dims[l]);
+    for (int l = 0; l < n_layers; ++l) {
+        ARGCHK(acts[l] >= GNN_ACT_LINEAR && acts[l] <= GNN_ACT_SOFTMAX, "unknown activation code %d", acts[l]);
+        ARGCHK(acts[l] != GNN_ACT_SOFTMAX || dims[l + 1] <= 1024, "softmax width %d too large", dims[l + 1]);
+    }
+    HIPCHK(hipSetDevice(device));
+    gnn_mlp *m = new gnn_mlp();
+    m->device = device; m->n_layers = n_layers; m->eps = bn_eps; m->has_bn = bn != nullptr;
+    m->dims.assign(dims, dims + n_layers + 1);
+    m->acts.assign(acts, acts + n_layers);
+    m->W.assign(n_layers, nullptr);
+    m->b.assign(n_layers, nullptr);
+    int rc = 0;
+    for (int l = 0; l < n_layers && !rc; ++l) {
+        rc = dev_alloc(&m->W[l], (size_t)dims[l] * dims[l + 1]);
+        if (!rc) rc = dev_alloc(&m->b[l], (size_t)dims[l + 1]);
+    }
+    if (!rc && m->has_bn) { rc = dev_alloc(&m->bn_scale, (size_t)dims[n_layers]); if (!rc) rc = dev_alloc(&m->bn_shift, (size_t)dims[n_layers]); }
+    if (!rc) rc = mlp_upload(m, W, b, bn);
+    if (rc) { gnn_mlp_destroy(m); return rc; }
+    *out = m;
+    return GNN_OK;
+}
+
+extern "C" int gnn_mlp_set_weights(gnn_mlp *m, const float *const *W, const float *const *b, const float *bn)
+{
+    ARGCHK(m && W && b, "bad arguments");
+    HIPCHK(hipSetDevice(m->device));
+    return mlp_upload(m, W, b, bn);
+}
+
+extern "C" int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y)
+{
+    ARGCHK(m && n_rows >= 0 && (n_rows == 0 || (x && y)), "bad arguments");
+    if (n_rows == 0) return GNN_OK;
+    HIPCHK(hipSetDevice(m->device));
+    int maxw = 1;
+    for (int l = 1; l <= m->n_layers; ++l) maxw = std::max(maxw, m->dims[l]);
+    float *dx = nullptr, *dy = nullptr, *t0 = nullptr, *t1 = nullptr;
+    int rc = dev_upload(&dx, x, (size_t)n_rows * m->dims[0]);
+    if (!rc) rc = dev_alloc(&dy, (size_t)n_rows * m->dims.back());
+    if (!rc) rc = dev_alloc(&t0, (size_t)n_rows * maxw);
+    if (!rc) rc = dev_alloc(&t1, (size_t)n_rows * maxw);
+    if (!rc) rc = launch_mlp(nullptr, m, n_rows, dx, m->dims[0], dy, m->dims.back(), t0, t1, nullptr, 1);
+    if (!rc) {
+        hipError_t e = hipMemcpy(y, dy, sizeof(float) * (size_t)n_rows * m->dims.back(), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "copy back: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(t0); (void)hipFree(t1);
+    return rc;
+}
+
+extern "C" int gnn_mlp_destroy(gnn_mlp *m)
+{
+    if (!m) return GNN_OK;
+    (void)hipSetDevice(m->device);
+    for (float *p : m->W) (void)hipFree(p);
+    for (float *p : m->b) (void)hipFree(p);
+    (void)hipFree(m->bn_scale); (void)hipFree(m->bn_shift);
+    gnn_fused_release(m);
+    delete m;
+    return GNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RCCL (loaded lazily so that the library itself has no link-time dependency on it)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Id128 { char b[128]; };   // ncclUniqueId, passed by value
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+}   // namespace
+static Rccl g_rccl;
+enum { NCCL_INT32 = 2, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_MAX = 2 };
+
+static int rccl_load()
+{
+    if (g_rccl.h) return GNN_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return gnn_fail(GNN_ERR_COMM, "cannot load librccl: %s", dlerror());
+#define SYM(field, name)                                                         \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                                  \
+    if (!g_rccl.field) return gnn_fail(GNN_ERR_COMM, "librccl lacks %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather") SYM(AllReduce, "ncclAllReduce") SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.h = h;
+    return GNN_OK;
+}
+
+#define NCCLCHK(expr)                                                                                   \
+    do {                                                                                                \
+        int r_ = (expr);                                                                                \
+        if (r_ != 0) return gnn_fail(GNN_ERR_COMM, "%s -> %s", #expr, g_rccl.GetErrorString(r_));      \
+    } while (0)
+
+extern "C" int gnn_comm_unique_id(uint8_t id[128])
+{
+    ARGCHK(id, "id is NULL");
+    int rc = rccl_load();
+    if (rc) return rc;
+    NCCLCHK(g_rccl.GetUniqueId(id));
+    return GNN_OK;
+}
+
+extern "C" int gnn_comm_create(const uint8_t id[128], int rank, int world, int device, gnn_comm **out)
+{
+    ARGCHK(id && out && world >= 1 && rank >= 0 && rank < world, "bad arguments");
+    *out = nullptr;
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(device));
+    gnn_comm *c = new gnn_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    Id128 uid;
+    memcpy(uid.b, id, 128);
+    int r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
+    if (r != 0) { delete c; return gnn_fail(GNN_ERR_COMM, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r)); }
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&c->scratch, sizeof(double)));
+    *out = c;
+    return GNN_OK;
+}
+
+extern "C" int gnn_comm_allreduce_max(gnn_comm *c, double *value)
+{
+    ARGCHK(c && value, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(g_rccl.AllReduce(c->scratch, c->scratch, 1, NCCL_FLOAT64, NCCL_MAX, c->nccl, c->stream));
+    HIPCHK(hipMemcpyAsync(value, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GNN_OK;
+}
+
+extern "C" int gnn_comm_destroy(gnn_comm *c)
+{
+    if (!c) return GNN_OK;
+    (void)hipSetDevice(c->device);
+    if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    (void)hipFree(c->scratch);
+    delete c;
+    return GNN_OK;
+}
+
+extern "C" int gnn_shard_range(int64_t n_nodes, int rank, int world, int64_t *row_begin, int64_t *n_rows)
+{
+    ARGCHK(n_nodes > 0 && world >= 1 && rank >= 0 && rank < world && row_begin && n_rows, "bad arguments");
+    const int64_t shard = ((n_nodes + world - 1) / world + 31) / 32 * 32;   // whole 32-node tiles per rank
+    const int64_t b = std::min<int64_t>(n_nodes, shard * rank), e = std::min<int64_t>(n_nodes, shard * (rank + 1));
+    *row_begin = b;
+    *n_rows = e - b;
+    return GNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// loop
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_output, int state_dim, int max_iter,
+                               float threshold, gnn_comm *comm, gnn_loop **out)
+{
+    ARGCHK(out, "out is NULL");
+    *out = nullptr;
+    ARGCHK(g && net_state && net_output, "graph and both MLPs are required");
+    ARGCHK(state_dim >= 0, "param <state_vect_dim> must be int>=0");           // GNN/GNN.py:53
+    ARGCHK(max_iter >= 0 && max_iter <= 100000, "max_iteration=%d out of range", max_iter);
+    ARGCHK(g->device == net_state->device && g->device == net_output->device, "handles live on different devices");
+    const int Ds = state_dim ? state_dim : g->NL;
+    const int NLc = state_dim ? g->NL : 0;
+    const int in_s = Ds + NLc + Ds + NLc + g->AL;                              // GNN/MLP.py:104
+    ARGCHK(net_state->dims[0] == in_s, "net_state input width %d != AL + 2*(NL + D) = %d", net_state->dims[0], in_s);
+    ARGCHK(net_state->dims.back() == Ds, "net_state output width %d != state width %d", net_state->dims.back(), Ds);
+    ARGCHK(net_output->dims[0] == Ds + NLc, "net_output input width %d != NL + D = %d", net_output->dims[0], Ds + NLc);
+    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    int64_t rb = 0, nr = 0;
+    gnn_shard_range(g->N, rank, world, &rb, &nr);
+    ARGCHK(rb == g->row_begin && nr == g->n_rows, "graph owns rows [%lld,+%lld) but rank %d/%d must own [%lld,+%lld)",
+           (long long)g->row_begin, (long long)g->n_rows, rank, world, (long long)rb, (long long)nr);
+    ARGCHK(!comm || comm->device == g->device, "communicator and graph live on different devices");
+
+    HIPCHK(hipSetDevice(g->device));
+    gnn_loop *l = new gnn_loop();
+    l->g = g; l->st = net_state; l->ou = net_output; l->comm = comm; l->device = g->device; l->rank = rank; l->world = world;
+    l->D = state_dim; l->Ds = Ds; l->NLc = NLc; l->in_s = in_s; l->wf = Ds + NLc; l->T = net_output->dims.back();
+    l->max_iter = max_iter; l->thr = threshold;
+    l->shard_rows = ((g->N + world - 1) / world + 31) / 32 * 32;
+    l->N_pad = l->shard_rows * world;
+    int rc = 0;
+    if (comm) l->stream = comm->stream;
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete l; return gnn_fail(GNN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    }
+    int maxw_s = 1, maxw_o = 1;
+    for (int i = 1; i <= net_state->n_layers; ++i) maxw_s = std::max(maxw_s, net_state->dims[i]);
+    for (int i = 1; i <= net_output->n_layers; ++i) maxw_o = std::max(maxw_o, net_output->dims[i]);
+    for (int b = 0; b < 2 && !rc; ++b) {
+        rc = dev_alloc(&l->state[b], (size_t)l->N_pad * Ds);
+        if (!rc && hipMemset(l->state[b], 0, sizeof(float) * (size_t)l->N_pad * Ds) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "memset");
+    }
+    if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world);
+    if (!rc) rc = dev_alloc(&l->kfinal_dev, 1);
+    if (!rc && hipHostMalloc((void **)&l->kfinal_host, sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
+    if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
+    if (!rc) rc = dev_alloc(&l->out, (size_t)g->n_masked * l->T);
+    for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], (size_t)g->n_masked * maxw_o);
+    if (!rc && hipEventCreate(&l->ev_total[0]) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipEventCreate");
+    if (!rc && hipEventCreate(&l->ev_total[1]) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipEventCreate");
+    if (rc) { gnn_loop_destroy(l); return rc; }
+    l->impl_req = 1;
+    (void)maxw_s;
+    *out = l;
+    return GNN_OK;
+}
+
+static int loop_ensure_unfused(gnn_loop *l)
+{
+    if (l->inp) return GNN_OK;
+    int maxw = 1;
+    for (int i = 1; i <= l->st->n_layers; ++i) maxw = std::max(maxw, l->st->dims[i]);
+    int rc = dev_alloc(&l->inp, (size_t)l->g->n_rows * l->in_s);
+    for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->tmp[b], (size_t)l->g->n_rows * maxw);
+    return rc;
+}
+
+extern "C" int gnn_loop_set_impl(gnn_loop *l, int impl, int *used)
+{
+    ARGCHK(l && (impl == 0 || impl == 1), "impl must be 0 (unfused) or 1 (fused when supported)");
+    l->impl_req = impl;
+    if (used) *used = (impl == 1 && gnn_fused_supported(l)) ? 1 : 0;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_set_profiling(gnn_loop *l, int enable)
+{
+    ARGCHK(l, "loop is NULL");
+    l->profiling = enable != 0;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *avg_iter_ms, int *n_iter_timed)
+{
+    ARGCHK(l, "loop is NULL");
+    if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    if (total_ms) *total_ms = l->total_ms;
+    if (avg_iter_ms) *avg_iter_ms = l->avg_iter_ms;
+    if (n_iter_timed) *n_iter_timed = l->n_iter_timed;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_set_state0(gnn_loop *l, const float *state0, uint64_t seed)
+{
+    ARGCHK(l, "loop is NULL");
+    HIPCHK(hipSetDevice(l->device));
+    const gnn_graph *g = l->g;
+    const size_t cnt = (size_t)g->n_rows * l->Ds;
+    if (!l->state_init && l->D) { int rc = dev_alloc(&l->state_init, cnt); if (rc) return rc; }
+    float *own = l->state_init;
+    if (l->D == 0) {   // state <- node labels (GNN.py:265); taken from the graph at run time
+        l->have_state0 = true;
+        return GNN_OK;
+    }
+    if (state0) {
+        HIPCHK(hipMemcpyAsync(own, state0, cnt * sizeof(float), hipMemcpyHostToDevice, l->stream));
+        HIPCHK(hipStreamSynchronize(l->stream));
+    } else if (cnt) {
+        hipLaunchKernelGGL(k_randn, cdiv((int64_t)cnt, 256), 256, 0, l->stream, (int64_t)cnt, (int64_t)g->row_begin * l->Ds, seed, 0.1f, own);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(l->stream));
+    }
+    l->have_state0 = true;
+    return GNN_OK;
+}
+
+static int loop_allgather(gnn_loop *l, float *state_buf, int *flag_row)
+{
+    if (l->world == 1) return GNN_OK;
+    const size_t cnt = (size_t)l->shard_rows * l->Ds;
+    NCCLCHK(g_rccl.GroupStart());
+    if (state_buf) NCCLCHK(g_rccl.AllGather(state_buf + cnt * l->rank, state_buf, cnt, NCCL_FLOAT32, l->comm->nccl, l->stream));
+    if (flag_row) NCCLCHK(g_rccl.AllGather(flag_row + l->rank, flag_row, 1, NCCL_INT32, l->comm->nccl, l->stream));
+    NCCLCHK(g_rccl.GroupEnd());
+    return GNN_OK;
+}
+
+static int unfused_iteration(gnn_loop *l, int k)
+{
+    const gnn_graph *g = l->g;
+    const int cur = k & 1, nxt = cur ^ 1, P = l->world;
+    const int *gate = l->flags + (size_t)k * P;
+    const float *own_cur = l->state[cur] + (size_t)g->row_begin * l->Ds;
+    float *own_nxt = l->state[nxt] + (size_t)g->row_begin * l->Ds;
+    // node_components (GNN.py:228): own state into columns [0, Ds) of the concat
+    if (g->n_rows)
+        HIPCHK(hipMemcpy2DAsync(l->inp, sizeof(float) * l->in_s, own_cur, sizeof(float) * l->Ds, sizeof(float) * l->Ds,
+                                (size_t)g->n_rows, hipMemcpyDeviceToDevice, l->stream));
+    // aggregated_states (GNN.py:234) into columns [Ds + NLc, +Ds)
+    int rc = launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
+                         l->inp + l->Ds + l->NLc, l->in_s, gate, P);
+    if (rc) return rc;
+    // net_state (GNN.py:240)
+    rc = launch_mlp(l->stream, l->st, g->n_rows, l->inp, l->in_s, own_nxt, l->Ds, l->tmp[0], l->tmp[1], gate, P);
+    if (rc) return rc;
+    // condition for the next body (GNN.py:206-218)
+    if (g->n_rows) {
+        hipLaunchKernelGGL(k_check, cdiv(g->n_rows, 256), 256, 0, l->stream, g->n_rows, l->Ds, own_nxt, own_cur, l->thr,
+                           l->flags + (size_t)(k + 1) * P + l->rank, gate, P);
+        HIPCHK(hipGetLastError());
+    }
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
+{
+    ARGCHK(l, "loop is NULL");
+    if (training) return gnn_fail(GNN_ERR_UNSUPPORTED, "training=True (backward through the loop) is not implemented on the device yet");
+    if (!l->have_state0) {
+        if (l->D == 0) l->have_state0 = true;
+        else return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
+    }
+    HIPCHK(hipSetDevice(l->device));
+    gnn_graph *g = l->g;
+    const int P = l->world;
+    hipStream_t st = l->stream;
+    const bool fused = l->impl_req == 1 && gnn_fused_supported(l);
+    l->impl_used = fused ? 1 : 0;
+    int rc = fused ? gnn_fused_prepare(l) : loop_ensure_unfused(l);
+    if (rc) return rc;
+    if (l->profiling && (int)l->ev.size() < 2 * l->max_iter) {
+        const size_t old = l->ev.size();
+        l->ev.resize(2 * (size_t)l->max_iter);
+        for (size_t i = old; i < l->ev.size(); ++i) HIPCHK(hipEventCreate(&l->ev[i]));
+    }
+
+    HIPCHK(hipEventRecord(l->ev_total[0], st));
+    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P, st));
+    float *own0 = l->state[0] + (size_t)g->row_begin * l->Ds;
+    if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
+        HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->row_begin * g->NL,
+                              sizeof(float) * (size_t)g->n_rows * l->Ds, hipMemcpyDeviceToDevice, st));
+    // first condition: state vs ones (GNN.py:266, :271)
+    if (g->n_rows) {
+        hipLaunchKernelGGL(k_check, cdiv(g->n_rows, 256), 256, 0, st, g->n_rows, l->Ds, own0, (const float *)nullptr, l->thr,
+                           l->flags + l->rank, (const int *)nullptr, 1);
+        HIPCHK(hipGetLastError());
+    }
+    if ((rc = loop_allgather(l, l->state[0], l->flags))) return rc;
+
+    // loop-invariant aggregates (GNN.py:259, :263)
+    if (!fused) {
+        const int c_nodes = l->Ds, c_aggn = l->Ds + l->NLc + l->Ds, c_agga = c_aggn + l->NLc;
+        rc = launch_spmm(st, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL, l->inp + c_agga, l->in_s, nullptr, 1);
+        if (rc) return rc;
+        if (l->D) {
+            rc = launch_spmm(st, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, l->inp + c_aggn, l->in_s, nullptr, 1);
+            if (rc) return rc;
+            if (g->n_rows)
+                HIPCHK(hipMemcpy2DAsync(l->inp + c_nodes, sizeof(float) * l->in_s, g->nodes + (size_t)g->row_begin * g->NL, sizeof(float) * g->NL,
+                                        sizeof(float) * g->NL, (size_t)g->n_rows, hipMemcpyDeviceToDevice, st));
+        }
+    }
+
+    for (int k = 0; k < l->max_iter; ++k) {
+        if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k], st));
+        rc = fused ? gnn_fused_iteration(l, k) : unfused_iteration(l, k);
+        if (rc) return rc;
+        if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k + 1], st));
+        if ((rc = loop_allgather(l, l->state[(k & 1) ^ 1], l->flags + (size_t)(k + 1) * P))) return rc;
+    }
+    hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, P, l->max_iter, l->kfinal_dev);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+
+    // apply_filters + net_output on the owned masked rows (GNN.py:275-279)
+    if (g->n_masked) {
+        const int64_t tot = g->n_masked * l->wf;
+        hipLaunchKernelGGL(k_feats, cdiv(tot, 256), 256, 0, st, g->n_masked, g->sh->masked_rows, l->state[0] + (size_t)g->row_begin * l->Ds,
+                           l->state[1] + (size_t)g->row_begin * l->Ds, l->kfinal_dev, l->Ds, g->nodes + (size_t)g->row_begin * g->NL, g->NL, l->NLc, l->feats);
+        HIPCHK(hipGetLastError());
+        rc = launch_mlp(st, l->ou, g->n_masked, l->feats, l->wf, l->out, l->T, l->otmp[0], l->otmp[1], nullptr, 1);
+        if (rc) return rc;
+    }
+    HIPCHK(hipEventRecord(l->ev_total[1], st));
+    HIPCHK(hipStreamSynchronize(st));
+    l->kfinal = *l->kfinal_host;
+    l->ran = true;
+    HIPCHK(hipEventElapsedTime(&l->total_ms, l->ev_total[0], l->ev_total[1]));
+    l->avg_iter_ms = 0.f;
+    l->n_iter_timed = 0;
+    if (l->profiling) {
+        double sum = 0;
+        for (int k = 0; k < l->kfinal; ++k) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, l->ev[2 * k], l->ev[2 * k + 1]));
+            sum += ms;
+        }
+        l->n_iter_timed = l->kfinal;
+        l->avg_iter_ms = l->kfinal ? (float)(sum / l->kfinal) : 0.f;
+    }
+    if (k_out) *k_out = (float)l->kfinal;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_get_state(const gnn_loop *l, float *state_out)
+{
+    ARGCHK(l && state_out, "bad arguments");
+    if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    HIPCHK(hipSetDevice(l->device));
+    const float *src = l->state[l->kfinal & 1] + (size_t)l->g->row_begin * l->Ds;
+    HIPCHK(hipMemcpy(state_out, src, sizeof(float) * (size_t)l->g->n_rows * l->Ds, hipMemcpyDeviceToHost));
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_get_output(const gnn_loop *l, float *out, int64_t *n_masked)
+{
+    ARGCHK(l, "loop is NULL");
+    if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    if (n_masked) *n_masked = l->g->n_masked;
+    if (out && l->g->n_masked) {
+        HIPCHK(hipSetDevice(l->device));
+        HIPCHK(hipMemcpy(out, l->out, sizeof(float) * (size_t)l->g->n_masked * l->T, hipMemcpyDeviceToHost));
+    }
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_readout(const gnn_loop *l, int G, const int32_t *ng_indptr, const int32_t *ng_node,
+                                const float *ng_w, float *out_graph)
+{
+    ARGCHK(l && G > 0 && ng_indptr && out_graph, "bad arguments");
+    if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    const int nnz = ng_indptr[G];
+    ARGCHK(ng_indptr[0] == 0 && nnz >= 0 && (nnz == 0 || (ng_node && ng_w)), "bad NodeGraph CSR");
+    for (int e = 0; e < nnz; ++e)
+        ARGCHK(ng_node[e] >= 0 && ng_node[e] < l->g->n_masked, "NodeGraph row %d but only %lld output rows (masks must be all-true for graph-based problems)",
+               ng_node[e], (long long)l->g->n_masked);
+    HIPCHK(hipSetDevice(l->device));
+    int32_t *dip = nullptr, *dn = nullptr;
+    float *dw = nullptr, *dout = nullptr;
+    int rc = dev_upload(&dip, ng_indptr, (size_t)G + 1);
+    if (!rc) rc = dev_upload(&dn, ng_node, (size_t)nnz);
+    if (!rc) rc = dev_upload(&dw, ng_w, (size_t)nnz);
+    if (!rc) rc = dev_alloc(&dout, (size_t)G * l->T);
+    if (!rc) {
+        hipLaunchKernelGGL(k_readout, cdiv((int64_t)G * l->T, 64), 64, 0, l->stream, G, l->T, dip, dn, dw, l->out, dout);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out_graph, dout, sizeof(float) * (size_t)G * l->T, hipMemcpyDeviceToHost, l->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
+        if (e != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "readout: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dip); (void)hipFree(dn); (void)hipFree(dw); (void)hipFree(dout);
+    return rc;
+}
+
+extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output)
+{
+    ARGCHK(dst && base && from, "bad arguments");
+    ARGCHK(dst->sh == base->sh, "dst must be derived from base");
+    if (!from->ran) return gnn_fail(GNN_ERR_STATE, "the source loop has not run");
+    ARGCHK(from->world == 1, "LGNN relabelling of sharded graphs is not supported");
+    ARGCHK(from->g->sh == base->sh, "the source loop ran on an unrelated graph");
+    const int extra = (get_state ? from->Ds : 0) + (get_output ? from->T : 0);
+    ARGCHK(dst->NL == base->base_NL + extra, "dst label width %d != %d + %d", dst->NL, base->base_NL, extra);
+    HIPCHK(hipSetDevice(dst->device));
+    // base labels are the first base_NL columns of base->nodes only when base is not itself derived
+    ARGCHK(base->NL == base->base_NL, "base must be the original (underived) graph (LGNN.py:287)");
+    const int64_t tot = dst->N * dst->NL;
+    hipLaunchKernelGGL(k_relabel, cdiv(tot, 256), 256, 0, from->stream, dst->N, base->NL, base->nodes, from->Ds, from->state[0], from->state[1],
+                       from->kfinal_dev, get_state, from->T, from->out, base->sh->mask, graph_mask_pos(base), get_output, dst->nodes, dst->NL);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(from->stream));
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_destroy(gnn_loop *l)
+{
+    if (!l) return GNN_OK;
+    (void)hipSetDevice(l->device);
+    for (int b = 0; b < 2; ++b) { (void)hipFree(l->state[b]); (void)hipFree(l->tmp[b]); (void)hipFree(l->otmp[b]); }
+    (void)hipFree(l->inp); (void)hipFree(l->inv); (void)hipFree(l->state_init); (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->flags); (void)hipFree(l->kfinal_dev);
+    if (l->kfinal_host) (void)hipHostFree(l->kfinal_host);
+    for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
+    if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
+    delete l;
+    return GNN_OK;
+}

@@ -1,0 +1,130 @@
+/*
+ * gnn_hip.h - C ABI of the MI355X (gfx950) engine for the GNN fixed-point state-propagation loop.
+ *
+ * The reference (sailab-code/GNN_tf_2.x) has no FFI / plugin boundary: the path is Python calling TensorFlow ops
+ * (SURVEY.md 8b).  The entry points below are what a binding for that path needs; each one names the reference
+ * interface it replaces (paths relative to the reference root).  The reference-side ctypes stub is in INTEGRATION.md;
+ * the Python mirror of the reference classes lives in gnn_tf_2.x_amd/GNN/.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative gnn_status otherwise; gnn_last_error() gives the text
+ *     (thread-local, valid until the next failing call on the thread).  Nothing throws or aborts across the ABI.
+ *   - host buffers are caller-owned, C-contiguous, float32 / int32 / uint8, and only read during the call;
+ *     outputs are written into caller-allocated buffers.
+ *   - device memory is owned by the handles (create .. destroy).  Handles are not thread-safe; different handles may
+ *     be used from different host threads.  All work of a loop runs on that loop's HIP stream.
+ *   - sparse operands are the TRANSPOSED, row-major reordered matrices of GraphTensor (GNN/graph_class.py:355-372)
+ *     in CSR form "by destination node": one indptr shared by Adjacency^T (inner order: ascending source id) and
+ *     ArcNode^T (inner order: ascending arc id).
+ */
+#ifndef GNN_HIP_H
+#define GNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GNN_OK = 0,
+    GNN_ERR_ARG = -1,      /* bad argument / inconsistent dimensions (reference: ValueError / TypeError) */
+    GNN_ERR_HIP = -2,      /* HIP runtime error (no device, out of memory, launch failure) */
+    GNN_ERR_STATE = -3,    /* call order (e.g. fetching results before gnn_loop_run) */
+    GNN_ERR_COMM = -4,     /* RCCL error */
+    GNN_ERR_UNSUPPORTED = -5
+} gnn_status;
+
+/* activation codes of Dense layers built by GNN/MLP.py:11-64 (Keras names) */
+typedef enum {
+    GNN_ACT_LINEAR = 0, GNN_ACT_RELU = 1, GNN_ACT_SELU = 2, GNN_ACT_ELU = 3,
+    GNN_ACT_TANH = 4, GNN_ACT_SIGMOID = 5, GNN_ACT_SOFTMAX = 6
+} gnn_activation;
+
+typedef struct gnn_graph gnn_graph;   /* device-resident GraphTensor (GNN/graph_class.py:330-372) */
+typedef struct gnn_mlp gnn_mlp;       /* device-resident Sequential built by GNN/MLP.py:11-64 */
+typedef struct gnn_loop gnn_loop;     /* one configured GNN.Loop (GNN/GNN.py:251-280) with its workspaces */
+typedef struct gnn_comm gnn_comm;     /* RCCL communicator for node-range sharding (no reference counterpart) */
+
+const char *gnn_last_error(void);
+int gnn_version(void);                               /* ABI version, currently 1 */
+int gnn_device_count(int *count);                    /* number of visible HIP devices (0 is not an error) */
+int gnn_device_synchronize(int device);
+
+/* ---- graph ------------------------------------------------------------------------------------------------------
+ * Replaces GraphTensor.__init__ / fromGraphObject (GNN/graph_class.py:331-363).
+ *   n_nodes            N, global node count
+ *   row_begin, n_rows  destination rows owned by this handle ([0, N) unless sharded across GPUs)
+ *   indptr[n_rows+1]   CSR row pointers of the owned rows, indptr[0] == 0
+ *   adj_src, adj_w     Adjacency^T entries of the owned rows: global source id and weight, ascending source id
+ *   arc_w, arc_labels  ArcNode^T entries of the owned rows in ascending arc id order: weight and the arc's label
+ *                      row arcs[arc, 2:] (already permuted into this order), [n_arcs, dim_arc_label]
+ *   nodes              node labels of ALL N nodes [N, dim_node_label] (neighbour labels are aggregated, GNN.py:263)
+ *   mask               set_mask & output_mask of the owned rows (GNN.py:275), uint8 [n_rows]
+ */
+int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_rows, int64_t n_arcs, const int32_t *indptr,
+                     const int32_t *adj_src, const float *adj_w, const float *arc_w, const float *arc_labels,
+                     int dim_arc_label, const float *nodes, int dim_node_label, const uint8_t *mask, int device,
+                     gnn_graph **out);
+/* LGNN.update_graph (GNN/LGNN.py:227-260) for node/graph-based layers, on the device:
+ * dst.nodes <- [base.nodes | state of `from` (if get_state) | scatter(mask, output of `from`) (if get_output)].
+ * `dst` must have been created by gnn_graph_derive(base, extra) with extra = get_state*Ds + get_output*T. */
+int gnn_graph_derive(const gnn_graph *base, int extra_node_label_dims, gnn_graph **out);
+int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output);
+int gnn_graph_get_nodes(const gnn_graph *g, float *nodes_out /* [N, dim_node_label] */);
+int gnn_graph_dims(const gnn_graph *g, int64_t *n_nodes, int64_t *n_rows, int64_t *n_arcs, int *dim_node_label,
+                   int *dim_arc_label, int64_t *n_masked);
+int gnn_graph_destroy(gnn_graph *g);
+
+/* ---- MLP --------------------------------------------------------------------------------------------------------
+ * Replaces the Keras Sequential of GNN/MLP.py:62-64 at inference: Dense(act) x n_layers [+ BatchNormalization].
+ * Weights in Keras get_weights() layout (GNN/GNN.py:163-165): W[l] row-major [dims[l], dims[l+1]], b[l] [dims[l+1]];
+ * bn = [gamma | beta | moving_mean | moving_variance], each dims[n_layers] long, or NULL without BatchNormalization. */
+int gnn_mlp_create(int n_layers, const int32_t *dims, const int32_t *acts, const float *const *W, const float *const *b,
+                   const float *bn, float bn_eps, int device, gnn_mlp **out);
+int gnn_mlp_set_weights(gnn_mlp *m, const float *const *W, const float *const *b, const float *bn);   /* GNN.py:168-172 */
+int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y);   /* Sequential.__call__(x, training=False) */
+int gnn_mlp_destroy(gnn_mlp *m);
+
+/* ---- loop -------------------------------------------------------------------------------------------------------
+ * Replaces GNNnodeBased.Loop (GNN/GNN.py:251-280): condition :202-220, convergence :223-242, apply_filters :245-248.
+ *   state_dim      state_vect_dim (0: state is initialised with the node labels, GNN.py:265)
+ *   max_iter, thr  max_iteration, state_threshold (GNN.py:61-62)
+ * gnn_loop_set_state0: injected initial state [n_rows owned, state_dim] (the reference draws tf.random.normal(stddev=0.1),
+ * GNN.py:262, whose stream cannot be reproduced); NULL draws N(0, 0.1^2) from the engine's own counter RNG with `seed`.
+ * gnn_loop_run: runs the whole loop on the device; the only host synchronisation is at its end.  *k_out = number of
+ * executed iterations as float (GNN.py:267).  training != 0 is GNN_ERR_UNSUPPORTED (backward pass: SURVEY.md 8f).
+ */
+int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_output, int state_dim, int max_iter, float threshold,
+                    gnn_comm *comm /* NULL: single GPU */, gnn_loop **out);
+int gnn_loop_set_state0(gnn_loop *l, const float *state0, uint64_t seed);
+int gnn_loop_run(gnn_loop *l, int training, float *k_out);
+int gnn_loop_get_state(const gnn_loop *l, float *state_out /* [n_rows, Ds] */);
+int gnn_loop_get_output(const gnn_loop *l, float *out /* [n_masked, T] */, int64_t *n_masked);
+/* GNNgraphBased.Loop readout (GNN/GNN.py:331-332, LGNN.py:278): out_graph = NodeGraph^T . out_nodes.
+ * NodeGraph^T is passed in CSR form over graphs: ng_indptr[G+1], ng_node (ascending), ng_w. */
+int gnn_loop_readout(const gnn_loop *l, int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node,
+                     const float *ng_w, float *out_graph /* [G, T] */);
+/* selects the implementation: 0 = unfused reference kernels (one kernel per TF op), 1 = fused gather+MLP kernel
+ * when the shapes allow it (default), falling back to 0 otherwise.  *used (may be NULL) reports the choice. */
+int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);
+/* per-kernel HIP-event timing of the last gnn_loop_run when profiling was enabled:
+ * avg_iter_ms = mean duration of the per-iteration kernel(s), total_ms = whole loop on the stream. */
+int gnn_loop_set_profiling(gnn_loop *l, int enable);
+int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *avg_iter_ms, int *n_iter_timed);
+int gnn_loop_destroy(gnn_loop *l);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------------------------------------------------
+ * Nodes are sharded by contiguous ranges; every iteration ends with one grouped RCCL all-gather of the owned state
+ * rows and the owned convergence flag.  The 128-byte id is produced on rank 0 and handed to the other ranks by the
+ * caller (file, socket, torch.distributed store ...). */
+int gnn_shard_range(int64_t n_nodes, int rank, int world, int64_t *row_begin, int64_t *n_rows);   /* owned rows of a rank */
+int gnn_comm_unique_id(uint8_t id[128]);
+int gnn_comm_create(const uint8_t id[128], int rank, int world, int device, gnn_comm **out);
+int gnn_comm_allreduce_max(gnn_comm *c, double *value);   /* barrier + max over ranks (bench timing) */
+int gnn_comm_destroy(gnn_comm *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNN_HIP_H */

@@ -1,0 +1,294 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libgnn_hip.so), against the oracle on the same seeded
+inputs.  Bar: the C oracle pins the floating-point evaluation order, so states / outputs / iteration counts must be
+BIT-IDENTICAL to it (np.array_equal); against the float64 shadow the tolerance is 1e-5 absolute (BASELINE.json
+north_star) on contractive state maps."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as corc
+from oracle import gnn_oracle as orc
+from util import make_mlp, random_arcs
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'graph_fixtures.npz'))
+
+
+def _engine():
+    from GNN import _engine
+    return _engine
+
+
+def _device_graph(g):
+    e = _engine()
+    mask = np.logical_and(g['set_mask'], g['output_mask'])
+    arc_labels = np.asarray(g['arcs'], np.float32)[:, 2:]
+    return e.Graph(g['nodes'].shape[0], g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], arc_labels[g['arcT'][1]],
+                   g['nodes'], mask)
+
+
+def _run_hip(g, st, ou, d, max_it, thr, s0, impl=1):
+    e = _engine()
+    loop = e.Loop(_device_graph(g), e.Mlp(st['weights'], st['activations'], st['batch_normalization']),
+                  e.Mlp(ou['weights'], ou['activations'], ou['batch_normalization']), d, max_it, thr)
+    loop.set_impl(impl)
+    if d:
+        loop.set_state0(s0)
+    k = loop.run()
+    return k, loop.state(), loop.output()
+
+
+def _case(rng, n=300, d=8, nl=3, al=2, hidden=(16,), act='selu', gain=0.6, sort=True, mode='average', deg=3):
+    arcs = random_arcs(rng, n, deg * n, al, sort=sort)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, mode)
+    ds, nls = (d if d else nl), (nl if d else 0)
+    st = make_mlp(rng, al + 2 * (ds + nls), list(hidden) + [ds], act, gain=gain, bn_random=True)
+    ou = make_mlp(rng, ds + nls, [2], 'softmax', bn_random=True)
+    s0 = (0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None
+    return g, st, ou, s0
+
+
+@pytest.mark.parametrize('act', ['linear', 'relu', 'selu', 'elu', 'tanh', 'sigmoid', 'softmax'])
+@pytest.mark.parametrize('bn', [True, False])
+def test_mlp_forward_bit_exact(act, bn):
+    rng = np.random.default_rng(sum(map(ord, act)) + int(bn))
+    net = make_mlp(rng, 37, [65, 129, 11], act, batch_normalization=bn, bn_random=True)
+    x = (3 * rng.standard_normal((517, 37))).astype(np.float32)
+    x[0, :] = 0
+    x[1, :] = 50      # saturating inputs
+    x[2, :] = -50
+    y = _engine().Mlp(net['weights'], net['activations'], bn).forward(x)
+    assert np.array_equal(y, corc.mlp_forward(x, net['weights'], net['activations'], bn))
+    assert np.max(np.abs(y - orc.mlp_forward(x, net['weights'], net['activations'], bn, np.float64))) < 2e-4
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+@pytest.mark.parametrize('d,nl,al,hidden,act,mode,sort', [
+    (0, 3, 1, (), 'selu', 'average', True),            # BASELINE config 1 shape: in 7 -> [3]
+    (0, 14, 3, (32, 32), 'selu', 'average', True),     # MUTAG shape: 31 -> [32, 32, 14]
+    (8, 3, 2, (16,), 'tanh', 'sum', False),
+    (5, 2, 1, (7, 9), 'relu', 'normalized', False),
+    (64, 3, 1, (128, 128), 'selu', 'average', True),   # BASELINE config 3 shape: 135 -> [128, 128, 64]
+    (64, 5, 1, (128, 128), 'selu', 'average', True),   # LGNN layer > 0 shape: 139 -> [128, 128, 64]
+    (32, 4, 0, (64,), 'sigmoid', 'average', True),     # no arc labels
+])
+def test_loop_bit_exact_vs_c_oracle(impl, d, nl, al, hidden, act, mode, sort):
+    rng = np.random.default_rng(1000 + 7 * d + nl)
+    g, st, ou, s0 = _case(rng, n=700, d=d, nl=nl, al=al, hidden=hidden, act=act, sort=sort, mode=mode)
+    g['set_mask'] = rng.random(700) < 0.8
+    g['output_mask'] = rng.random(700) < 0.7
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 30, 0.01, s0)
+    k, s, o = _run_hip(g, st, ou, d, 30, 0.01, s0, impl)
+    assert k == kc
+    assert np.array_equal(s, sc)
+    assert o.shape == oc.shape and np.array_equal(o, oc)
+    k64, s64, o64 = orc.loop_node(g, st, ou, d, 30, 0.01, s0, np.float64)
+    assert k == k64
+    assert np.max(np.abs(s - s64)) < 1e-5 and np.max(np.abs(o - o64)) < 1e-5
+
+
+@pytest.mark.parametrize('impl', [0, 1])
+def test_loop_edge_cases(impl):
+    rng = np.random.default_rng(5)
+    g, st, ou, s0 = _case(rng, n=257, d=4, gain=1.0)
+    zero = dict(st, weights=[np.zeros_like(w) for w in st['weights'][:-4]] + [np.ones(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32), np.ones(4, np.float32)])
+    k, s, _ = _run_hip(g, zero, ou, 4, 30, 0.01, s0, impl)
+    assert k == 2 and np.all(s == 0)                               # zero net_state: converges at k == 2
+    k, s, o = _run_hip(g, st, ou, 4, 9, 0.0, s0, impl)
+    kc, sc, oc = corc.loop_node(g, st, ou, 4, 9, 0.0, s0)
+    assert k == kc == 9 and np.array_equal(s, sc) and np.array_equal(o, oc)   # threshold 0 -> max_iteration
+    k, s, o = _run_hip(g, st, ou, 4, 0, 0.01, s0, impl)
+    assert k == 0 and np.array_equal(s, s0)                        # max_iteration 0: body never runs
+    assert np.array_equal(o, corc.loop_node(g, st, ou, 4, 0, 0.01, s0)[2])
+    # state == ones at entry (D == 0 with all-ones labels): first condition is false
+    arcs = np.array([[0, 1, .5], [1, 0, .5]], dtype=np.float32)
+    g1 = orc.make_graph_dict(arcs, np.ones((3, 2), np.float32))    # node 2 is isolated
+    st1, ou1 = make_mlp(rng, 1 + 2 * 2, [2], 'linear'), make_mlp(rng, 2, [2], 'softmax')
+    assert _run_hip(g1, st1, ou1, 0, 5, 0.01, None, impl)[0] == 0
+    # isolated node + empty mask + no arcs at all
+    g2 = orc.make_graph_dict(arcs, rng.random((3, 2)).astype(np.float32))
+    g2['set_mask'] = np.zeros(3, bool)
+    k, s, o = _run_hip(g2, st1, ou1, 0, 5, 0.01, None, impl)
+    kc, sc, oc = corc.loop_node(g2, st1, ou1, 0, 5, 0.01, None, want_out=False)
+    assert k == kc and np.array_equal(s, sc) and o.shape == (0, 2)
+    g3 = orc.make_graph_dict(np.zeros((0, 3), np.float32), rng.random((5, 2)).astype(np.float32))
+    k, s, o = _run_hip(g3, st1, ou1, 0, 4, 0.01, None, impl)
+    kc, sc, oc = corc.loop_node(g3, st1, ou1, 0, 4, 0.01, None)
+    assert k == kc and np.array_equal(s, sc) and np.array_equal(o, oc)
+
+
+def test_iteration_count_tracks_threshold():
+    """k is decided on the device by the fused '>' test; sweep thresholds so that k changes and must track the oracle."""
+    rng = np.random.default_rng(8)
+    g, st, ou, s0 = _case(rng, n=500, d=16, hidden=(32,), gain=0.5)
+    seen = set()
+    for thr in [0.5, 0.1, 0.03, 0.01, 0.003, 1e-3, 1e-4]:
+        kc, sc, _ = corc.loop_node(g, st, ou, 16, 40, thr, s0)
+        k, s, _ = _run_hip(g, st, ou, 16, 40, thr, s0)
+        assert k == kc and np.array_equal(s, sc)
+        seen.add(k)
+    assert len(seen) >= 4
+
+
+def _models(st, ou, d, max_it, thr, cls):
+    from GNN.MLP import MLP
+    def build(net):
+        w = net['weights']
+        n_dense = len(net['activations'])
+        m = MLP(input_dim=w[0].shape[0], layers=[w[2 * i].shape[1] for i in range(n_dense)], activations=net['activations'],
+                kernel_initializer='zeros', bias_initializer='zeros', dropout_rate=0.1, dropout_pos=0,
+                batch_normalization=net['batch_normalization'])
+        m.set_weights(w)
+        return m
+    from GNN import losses
+    return cls(net_state=build(st), net_output=build(ou), optimizer=None, loss_function=losses.categorical_crossentropy,
+               loss_arguments=None, state_vect_dim=d, max_iteration=max_it, threshold=thr, addressed_problem='c')
+
+
+@pytest.mark.parametrize('prefix,mode', [('simple/average/n', 'average'), ('simple/sum/n', 'sum'), ('random/3', 'average'),
+                                         ('merge_n/normalized', 'normalized'), ('merge_n/average', 'average')])
+def test_facade_on_reference_fixtures(prefix, mode):
+    """GraphObject -> GraphTensor -> GNNnodeBased.Loop on graphs whose matrices were produced by the reference's own code."""
+    from GNN.GNN import GNNnodeBased
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(2)
+    arcs, nodes = GOLD[f'{prefix}/arcs'], GOLD[f'{prefix}/nodes']
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=GOLD[f'{prefix}/targets'], aggregation_mode=mode)
+    nl, al = go.DIM_NODE_LABEL, go.DIM_ARC_LABEL
+    scale = 1.0 / max(1.0, float(np.abs(nodes).max()))
+    st = make_mlp(rng, al + 2 * nl, [6, nl], 'tanh', gain=0.5 * scale)
+    ou = make_mlp(rng, nl, [2], 'softmax')
+    gnn = _models(st, ou, 0, 20, 0.01, GNNnodeBased)
+    k, s, o = gnn.Loop(go)
+    kc, sc, oc = corc.loop_node(orc.make_graph_dict(arcs, nodes, mode), st, ou, 0, 20, 0.01)
+    assert k == kc and np.array_equal(s, sc) and np.array_equal(o, oc)
+    assert np.array_equal(gnn(go), oc)
+    it, loss, targs, out = gnn.evaluate_single_graph(go, training=False)
+    assert it == kc and np.array_equal(out, oc) and targs.shape == oc.shape and np.isfinite(loss)
+    gnn.extra_metrics = {}
+    metrics = gnn.test(go)
+    assert metrics['It'] == int(kc) and np.isfinite(metrics['Loss'])
+
+
+def test_graph_based_readout_and_errors():
+    from GNN.GNN import GNNgraphBased, GNNnodeBased
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(4)
+    p = 'merge_g/average'
+    go = GraphObject(arcs=GOLD[f'{p}/arcs'], nodes=GOLD[f'{p}/nodes'], targets=GOLD[f'{p}/targets'], problem_based='g',
+                     NodeGraph=GOLD[f'{p}/NodeGraph'])
+    nl, al = go.DIM_NODE_LABEL, go.DIM_ARC_LABEL
+    st, ou = make_mlp(rng, al + 2 * nl, [8, nl], 'selu', gain=0.5), make_mlp(rng, nl, [2], 'softmax')
+    gnn = _models(st, ou, 0, 15, 0.01, GNNgraphBased)
+    k, s, o = gnn.Loop(go)
+    gd = orc.make_graph_dict(go.arcs, go.nodes, 'average', NodeGraph=go.NodeGraph)
+    kc, sc, on = corc.loop_node(gd, st, ou, 0, 15, 0.01)
+    assert k == kc and np.array_equal(s, sc)
+    assert o.shape == (3, 2) and np.array_equal(o, corc.readout(go.NodeGraph, on))
+    np.testing.assert_allclose(o, orc.loop_graph(gd, st, ou, 0, 15, 0.01, dtype=np.float64)[2], atol=1e-5)
+    node_only = GraphObject(arcs=go.arcs, nodes=go.nodes, targets=np.zeros((go.nodes.shape[0], 2)))
+    with pytest.raises(ValueError):
+        gnn.Loop(node_only)                                        # reference GNN.py:322
+    with pytest.raises(ValueError):
+        _models(st, make_mlp(rng, nl + 1, [2], 'softmax'), 0, 5, 0.01, GNNnodeBased).Loop(go)   # wrong net_output width
+
+
+def test_lgnn_stack_on_device():
+    from GNN.GNN import GNNnodeBased
+    from GNN.LGNN import LGNN
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(6)
+    arcs = random_arcs(rng, 400, 1200, 1)
+    nodes = (2 * rng.random((400, 3)) - 1).astype(np.float32)
+    set_mask = rng.random(400) < 0.75
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=np.zeros((400, 2)), set_mask=set_mask)
+    gd = orc.make_graph_dict(arcs, nodes, 'average', set_mask=set_mask)
+    for get_state, get_output in [(False, True), (True, True), (True, False)]:
+        layers, gnns, models = 3, [], []
+        for layer in range(layers):
+            ins, ls = orc.get_inout_dims('state', 3, 1, 2, 'n', 8, [16], layer=layer, get_state=get_state, get_output=get_output)
+            ino, lo = orc.get_inout_dims('output', 3, 1, 2, 'n', 8, None, layer=layer, get_state=get_state, get_output=get_output)
+            st, ou = make_mlp(rng, ins, ls, 'selu', gain=0.5), make_mlp(rng, ino, lo, 'softmax')
+            gnns.append(dict(net_state=st, net_output=ou, state_vect_dim=8, max_iteration=12, threshold=0.01))
+            models.append(_models(st, ou, 8, 12, 0.01, GNNnodeBased))
+        s0s = [(0.1 * rng.standard_normal((400, 8))).astype(np.float32) for _ in range(layers)]
+        lgnn = LGNN(models, get_state, get_output, None, None, None, 'c')
+        K, state, outs = lgnn.Loop(go, state0=s0s)
+        # bit-exact chain: C oracle per layer + the reference's relabelling rule
+        gtmp, Kc, outs_c = dict(gd), [], []
+        for gnn, s0 in zip(gnns, s0s):
+            kc, sc, oc = corc.loop_node(gtmp, gnn['net_state'], gnn['net_output'], 8, 12, 0.01, s0)
+            Kc.append(kc)
+            outs_c.append(oc)
+            gtmp = orc.update_graph(gd, sc, oc, get_state, get_output)
+        assert K == Kc and np.array_equal(state, sc)
+        for a, b in zip(outs, outs_c):
+            assert np.array_equal(a, b)
+        K64, s64, o64 = orc.lgnn_loop(gd, gnns, get_state, get_output, False, s0s, np.float64)
+        assert K == K64 and np.max(np.abs(outs[-1] - o64[-1])) < 1e-5
+        assert np.array_equal(lgnn(go), outs_c[-1]) and np.array_equal(lgnn.predict(go, 0), outs_c[0])
+
+
+def test_engine_rng_and_call_order_errors():
+    e = _engine()
+    rng = np.random.default_rng(9)
+    g, st, ou, _ = _case(rng, n=2048, d=8)
+    loop = e.Loop(_device_graph(g), e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 8, 0, 0.01)
+    with pytest.raises(e.EngineError):
+        loop.state()                                               # before run
+    with pytest.raises(e.EngineError):
+        loop.run()                                                 # state_vect_dim > 0 without state0
+    loop.set_state0(None, seed=3)
+    assert loop.run() == 0
+    s = loop.state()
+    assert abs(float(s.mean())) < 0.01 and abs(float(s.std()) - 0.1) < 0.01   # N(0, 0.1^2) as GNN.py:262
+    with pytest.raises(NotImplementedError):
+        loop.run(training=True)
+    with pytest.raises(ValueError):
+        e.Loop(_device_graph(g), e.Mlp(ou['weights'], ou['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 8, 5, 0.01)
+
+
+def test_full_size_properties():
+    """BASELINE config 3 size (1M nodes / ~10M arcs, D=64, 135->128->128->64): properties that do not need the oracle on
+    the full graph: sampled rows of one step against NumPy float64, run-to-run determinism, fused == unfused bit for bit."""
+    from GNN import GNN_utils as utils
+    e = _engine()
+    rng = np.random.default_rng(123)
+    s = utils.syntheticGraph(1_000_000, 10.0, seed=20261003)
+    n, d, nl, al = s['n_nodes'], 64, 3, 1
+    st = make_mlp(rng, al + 2 * (nl + d), [128, 128, d], 'selu')
+    ou = make_mlp(rng, nl + d, [2], 'softmax')
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    graph = e.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8))
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    results = {}
+    for impl in (1, 0):
+        loop = e.Loop(graph, mst, mou, d, 3, 0.0)
+        used = loop.set_impl(impl)
+        loop.set_state0(s0)
+        assert loop.run() == 3
+        results[impl] = (used, loop.state(), loop.output())
+        if impl == 1:
+            assert loop.run() == 3 and np.array_equal(loop.state(), results[1][1])     # deterministic
+        loop.close()
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][2], results[1][2])
+    # one step on a row sample, float64 NumPy: rows are independent given the previous iterate
+    loop = e.Loop(graph, mst, mou, d, 1, 0.0)
+    loop.set_state0(s0)
+    assert loop.run() == 1
+    s1 = loop.state()
+    rows = rng.choice(n, 3000, replace=False)
+    ip, src, w = s['indptr'], s['adj_src'], s['adj_w']
+    inp = np.zeros((len(rows), 135))
+    for t, r in enumerate(rows):
+        e0, e1 = ip[r], ip[r + 1]
+        inp[t, :64] = s0[r]
+        inp[t, 64:67] = s['nodes'][r]
+        inp[t, 67:131] = (w[e0:e1, None].astype(np.float64) * s0[src[e0:e1]]).sum(0)
+        inp[t, 131:134] = (w[e0:e1, None].astype(np.float64) * s['nodes'][src[e0:e1]]).sum(0)
+        inp[t, 134] = (s['arc_w'][e0:e1].astype(np.float64) * s['arc_labels_csr'][e0:e1, 0]).sum()
+    ref = orc.mlp_forward(inp, st['weights'], st['activations'], True, np.float64)
+    assert np.max(np.abs(s1[rows] - ref)) < 1e-5

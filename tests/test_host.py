@@ -1,0 +1,159 @@
+"""CPU-only checks of the product's host side: the Python mirror of the reference classes against the golden fixtures,
+and that the C-ABI library loads and exports every symbol declared in include/gnn_hip.h (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import gnn_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = np.load(os.path.join(ROOT, 'tests', 'golden', 'graph_fixtures.npz'))
+
+
+def _graph_object(prefix, problem_based='n', mode='average'):
+    from GNN.graph_class import GraphObject
+    kw = {}
+    if f'{prefix}/NodeGraph' in GOLD.files:
+        kw['NodeGraph'] = GOLD[f'{prefix}/NodeGraph']
+    return GraphObject(arcs=GOLD[f'{prefix}/arcs'], nodes=GOLD[f'{prefix}/nodes'], targets=GOLD[f'{prefix}/targets'],
+                       problem_based=problem_based, set_mask=GOLD[f'{prefix}/set_mask'], output_mask=GOLD[f'{prefix}/output_mask'],
+                       sample_weights=GOLD[f'{prefix}/sample_weights'], aggregation_mode=mode, **kw)
+
+
+@pytest.mark.parametrize('prefix,mode', [('simple/average/n', 'average'), ('simple/sum/n', 'sum'), ('simple/normalized/n', 'normalized'),
+                                         ('random/1', 'average'), ('random/5', 'average'), ('merge_n/normalized', 'normalized')])
+def test_graphobject_matrices_match_reference(prefix, mode):
+    from GNN.graph_class import GraphTensor
+    g = _graph_object(prefix, mode=mode)
+    an, ad = g.ArcNode.tocoo(), g.Adjacency.tocoo()
+    assert np.array_equal(an.row, GOLD[f'{prefix}/ArcNode_row']) and np.array_equal(an.col, GOLD[f'{prefix}/ArcNode_col'])
+    assert np.array_equal(an.data, GOLD[f'{prefix}/ArcNode_data'])
+    assert np.array_equal(ad.data, GOLD[f'{prefix}/Adj_data']) and np.array_equal(g.Adjacency.toarray(), GOLD[f'{prefix}/Adj_dense'])
+    assert g.DIM_NODE_LABEL == g.nodes.shape[1] and g.DIM_ARC_LABEL == g.arcs.shape[1] - 2 and g.DIM_TARGET == g.targets.shape[1]
+    gt = GraphTensor.fromGraphObject(g)
+    (ip, src, w), (ip2, aid, w2) = orc.graph_matrices(g.arcs, g.nodes.shape[0], mode)
+    assert np.array_equal(gt.Adjacency[0], ip) and np.array_equal(gt.Adjacency[1], src) and np.array_equal(gt.Adjacency[2], w)
+    assert np.array_equal(gt.ArcNode[0], ip2) and np.array_equal(gt.ArcNode[1], aid) and np.array_equal(gt.ArcNode[2], w2)
+
+
+def test_graphobject_merge_copy_save_load(tmp_path):
+    from GNN.graph_class import GraphObject, GraphTensor
+    parts = [_graph_object(f'gsingle/{i}', 'g') for i in range(3)]
+    m = GraphObject.merge(parts, problem_based='g', aggregation_mode='average')
+    for k in ('arcs', 'nodes', 'targets', 'set_mask', 'output_mask', 'sample_weights', 'NodeGraph'):
+        assert np.array_equal(getattr(m, k), GOLD[f'merge_g/average/{k}']), k
+    assert np.array_equal(m.ArcNode.tocoo().data, GOLD['merge_g/average/ArcNode_data'])
+    c = m.copy()
+    assert np.array_equal(c.arcs, m.arcs) and np.array_equal(c.NodeGraph, m.NodeGraph)
+    m.save(str(tmp_path / 'g'))
+    back = GraphObject.load(str(tmp_path / 'g'), problem_based='g', aggregation_mode='average')
+    assert np.array_equal(back.arcs, m.arcs) and np.array_equal(back.NodeGraph, m.NodeGraph) and np.array_equal(back.targets, m.targets)
+    ip, node, w = GraphTensor.fromGraphObject(m).nodegraph_csr()
+    dense = np.zeros_like(m.NodeGraph)
+    for gidx in range(len(ip) - 1):
+        dense[node[ip[gidx]:ip[gidx + 1]], gidx] = w[ip[gidx]:ip[gidx + 1]]
+    assert np.array_equal(dense, m.NodeGraph)
+    with pytest.raises(ValueError):
+        GraphObject(arcs=m.arcs, nodes=m.nodes, targets=m.targets, aggregation_mode='bogus')
+    with pytest.raises(ValueError):
+        GraphObject(arcs=m.arcs, nodes=m.nodes, targets=m.targets, set_mask=np.ones(3), output_mask=np.ones(4))
+    with pytest.raises(TypeError):
+        GraphObject.merge('nope', 'n', 'sum')
+
+
+def test_randomgraph_reproduces_reference_stream():
+    from GNN import GNN_utils as utils
+    for seed, n in [(1, 17), (2, 23), (5, 39)]:
+        np.random.seed(seed)
+        g = utils.randomGraph(nodes_number=n, dim_node_label=3, dim_arc_label=1, dim_target=2, density=0.7)
+        assert np.array_equal(g.arcs, GOLD[f'random/{seed}/arcs']) and np.array_equal(g.nodes, GOLD[f'random/{seed}/nodes'])
+        assert np.array_equal(g.targets, GOLD[f'random/{seed}/targets'])
+    s = utils.simple_graph('n')
+    assert np.array_equal(s.arcs, GOLD['simple/average/n/arcs']) and np.array_equal(s.targets, GOLD['simple/average/n/targets'])
+    np.random.seed(20261003)
+    many = [utils.randomGraph(int(np.random.choice(range(15, 40))), 3, 1, 2, 0.7) for _ in range(70)]
+    batches = utils.getbatches(many, problem_based='n', aggregation_mode='average', batch_size=32)
+    assert np.array_equal(np.array([[b.nodes.shape[0], b.arcs.shape[0]] for b in batches]), GOLD['getbatches/shapes'])
+    tr, te, va = utils.getindices(70, 0.7, 0.2, seed=3)
+    assert len(tr) == 49 and len(te) == 7 and len(va) == 14 and sorted(tr + te + va) == list(range(70))
+
+
+def test_synthetic_graph_invariants():
+    from GNN import GNN_utils as utils
+    s = utils.syntheticGraph(5000, 10.0, seed=7)
+    n, e = s['n_nodes'], s['n_arcs']
+    src, dst = s['src'].astype(np.int64), s['dst'].astype(np.int64)
+    assert 0.9 * 50000 < e <= 50000 and np.all(src != dst)
+    key = src * n + dst
+    assert np.all(np.diff(key) > 0)                                   # lexicographically sorted, duplicate free
+    assert np.array_equal(np.sort(dst * n + src), key)                # symmetric
+    arcs = np.concatenate([np.stack([src, dst], 1).astype(np.float32), s['arc_labels']], axis=1)
+    (ip, a_src, w), (_, aid, _) = orc.graph_matrices(arcs, n, 'average')
+    assert np.array_equal(ip, s['indptr']) and np.array_equal(a_src, s['adj_src']) and np.array_equal(aid, s['arc_perm'])
+    assert np.array_equal(w, s['adj_w']) and np.array_equal(s['arc_labels'][aid], s['arc_labels_csr'])
+
+
+def test_mlp_factory_and_dims():
+    from GNN.MLP import MLP, get_inout_dims, Dense, Dropout, BatchNormalization, set_seed
+    set_seed(0)
+    net = MLP(input_dim=7, layers=[5, 3], activations='selu', kernel_initializer='lecun_normal', bias_initializer='lecun_normal',
+              dropout_rate=0.1, dropout_pos=0)
+    kinds = [type(l) for l in net.layers]
+    assert kinds == [Dropout, Dense, Dense, BatchNormalization]        # dropout_pos 0 -> before the first Dense (MLP.py:54-55)
+    w = net.get_weights()
+    assert [a.shape for a in w] == [(7, 5), (5,), (5, 3), (3,), (3,), (3,), (3,), (3,)]
+    assert np.all(w[4] == 1) and np.all(w[5] == 0) and np.all(w[6] == 0) and np.all(w[7] == 1)
+    assert np.abs(w[0]).max() <= 2 * np.sqrt(1 / 7) / 0.87962566103423978 + 1e-6
+    net2 = MLP(4, [6, 6, 2], ['relu', 'tanh', 'softmax'], 'glorot_normal', 'zeros', dropout_rate=[0.1, 0.2], dropout_pos=[0, 2],
+               batch_normalization=False)
+    assert [type(l) for l in net2.layers] == [Dropout, Dense, Dense, Dropout, Dense]
+    assert net2.activations == ['relu', 'tanh', 'softmax'] and not net2.batch_normalization
+    with pytest.raises(ValueError):
+        MLP(4, [6, 2], ['relu'], 'zeros', 'zeros')
+    for args, kw in [(('state', 3, 1, 2, 'n', 64, [128, 128]), {}), (('output', 3, 1, 2, 'n', 64, None), {}),
+                     (('state', 3, 1, 2, 'n', 64, [128, 128]), dict(layer=2, get_output=True)),
+                     (('state', 3, 1, 2, 'n', 0, 5), dict(layer=2, get_state=True, get_output=True)),
+                     (('output', 3, 2, 4, 'a', 5, None), {}), (('state', 14, 3, 2, 'g', 0, [32, 32]), {})]:
+        assert get_inout_dims(*args, **kw) == orc.get_inout_dims(*args, **kw)
+
+
+def test_model_argument_errors_match_reference():
+    from GNN.GNN import GNNnodeBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import MLP
+    from GNN.GNN_BaseClass import BaseClass
+    st = MLP(7, [3], 'selu', 'lecun_normal', 'zeros')
+    ou = MLP(3, [2], 'softmax', 'glorot_normal', 'zeros')
+    mk = lambda **kw: GNNnodeBased(**{**dict(net_state=st, net_output=ou, optimizer=None, loss_function=None, loss_arguments=None,
+                                             state_vect_dim=0, max_iteration=5, threshold=0.01, addressed_problem='c'), **kw})
+    with pytest.raises(TypeError):
+        mk(state_vect_dim=-1)                       # reference GNN.py:53
+    with pytest.raises(ValueError):
+        mk(addressed_problem='x')                   # reference GNN_BaseClass.py:40
+    with pytest.raises(TypeError):
+        mk(extra_metrics=[1])                       # reference GNN_BaseClass.py:41
+    with pytest.raises(TypeError):
+        BaseClass.checktype(3)                      # reference GNN_BaseClass.py:424
+    assert BaseClass.checktype(None) is None
+    gnn = mk()
+    assert gnn.get_weights()[0][0][0].shape == (7, 3)
+    with pytest.raises(NotImplementedError):
+        gnn.train([], 1)
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'gnn_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(gnn_[a-z0-9_]+)\s*\(', header)))
+    assert len(declared) >= 28
+    from GNN import _engine
+    assert sorted(_engine.EXPORTS) == declared
+    so = _engine.LIB_PATH
+    assert os.path.exists(so), 'libgnn_hip.so not built: run __graft_entry__.build()'
+    lib = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.gnn_version.restype = ctypes.c_int
+    assert lib.gnn_version() == 1
