@@ -229,7 +229,19 @@ def test_lgnn_stack_on_device():
             assert np.array_equal(a, b)
         K64, s64, o64 = orc.lgnn_loop(gd, gnns, get_state, get_output, False, s0s, np.float64)
         assert K == K64 and np.max(np.abs(outs[-1] - o64[-1])) < 1e-5
-        assert np.array_equal(lgnn(go), outs_c[-1]) and np.array_equal(lgnn.predict(go, 0), outs_c[0])
+    # __call__ / predict on a stack without random initial states (state_vect_dim == 0: state starts from the labels)
+    gnns, models = [], []
+    for layer in range(2):
+        ins, ls = orc.get_inout_dims('state', 3, 1, 2, 'n', 0, [8], layer=layer, get_output=True)
+        ino, lo = orc.get_inout_dims('output', 3, 1, 2, 'n', 0, None, layer=layer, get_output=True)
+        st, ou = make_mlp(rng, ins, ls, 'tanh', gain=0.5), make_mlp(rng, ino, lo, 'softmax')
+        gnns.append(dict(net_state=st, net_output=ou, state_vect_dim=0, max_iteration=10, threshold=0.01))
+        models.append(_models(st, ou, 0, 10, 0.01, GNNnodeBased))
+    lgnn = LGNN(models, False, True, None, None, None, 'c')
+    k0, s0_, o0 = corc.loop_node(gd, gnns[0]['net_state'], gnns[0]['net_output'], 0, 10, 0.01)
+    k1, s1_, o1 = corc.loop_node(orc.update_graph(gd, s0_, o0, False, True), gnns[1]['net_state'], gnns[1]['net_output'], 0, 10, 0.01)
+    assert np.array_equal(lgnn(go), o1) and np.array_equal(lgnn.predict(go, 0), o0)
+    assert [np.array_equal(a, b) for a, b in zip(lgnn.predict(go, 'all'), [o0, o1])] == [True, True]
 
 
 def test_engine_rng_and_call_order_errors():
