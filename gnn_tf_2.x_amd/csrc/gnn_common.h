@@ -67,13 +67,26 @@ __device__ __forceinline__ float gnn_act(float v, int act)
     }
 }
 
-// iteration gate: flags[k*P .. k*P+P) hold, per rank, "some owned node has not converged"; body k runs iff any is set
+// Iteration gate.  flags[k][rank][slot * GNN_FLAG_STRIDE] != 0 means "some node owned by `rank` had not converged when
+// body k was about to run"; body k runs iff any slot of any rank is set.  Writers spread their atomicOr over
+// GNN_FLAG_SLOTS words on separate 128-byte lines (slot = blockIdx & 15) so that ~10^4 workgroups do not queue on one
+// address.
+#define GNN_FLAG_SLOTS 16
+#define GNN_FLAG_STRIDE 32
+#define GNN_FLAG_WORDS (GNN_FLAG_SLOTS * GNN_FLAG_STRIDE)   // ints per (iteration, rank)
+
 __device__ __forceinline__ bool gnn_gate_open(const int *gate, int world)
 {
     if (!gate) return true;
     int any = 0;
-    for (int p = 0; p < world; ++p) any |= gate[p];
+    for (int p = 0; p < world * GNN_FLAG_SLOTS; ++p) any |= gate[p * GNN_FLAG_STRIDE];
     return any != 0;
+}
+
+__device__ __forceinline__ void gnn_flag_raise(int *flag_rank_base)
+{
+    int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(w, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -132,7 +145,7 @@ struct gnn_loop {
     float *inv = nullptr;                   // fused: loop-invariant label block [n_rows, inv_w]
     float *tmp[2] = {nullptr, nullptr};     // unfused: layer activations
     float *feats = nullptr, *out = nullptr, *otmp[2] = {nullptr, nullptr};
-    int *flags = nullptr;                   // [(max_iter+1) * world]
+    int *flags = nullptr;                   // [(max_iter+2), world, GNN_FLAG_WORDS]
     int *kfinal_dev = nullptr, *kfinal_host = nullptr;
     int kfinal = -1;
     bool have_state0 = false, ran = false;
@@ -143,6 +156,10 @@ struct gnn_loop {
     float total_ms = 0.f, avg_iter_ms = 0.f;
     int n_iter_timed = 0;
 };
+
+// gnn_engine.hip
+int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const int32_t *idx, const float *w, const float *X,
+                    int width, int64_t ldx, float *out, int64_t ldo, const int *gate, int world);
 
 // gnn_fused.hip
 bool gnn_fused_supported(const gnn_loop *l);

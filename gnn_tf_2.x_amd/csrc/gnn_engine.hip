@@ -225,7 +225,7 @@ __global__ void k_check(int64_t n_rows, int d, const float *__restrict__ s, cons
         const float rhs = thr * rn;
         f = lhs > rhs;
     }
-    if (__any(f) && (threadIdx.x & 63) == 0) atomicOr(flag_out, 1);
+    if (__any(f) && (threadIdx.x & 63) == 0) gnn_flag_raise(flag_out);
 }
 
 // k_final = number of executed bodies = first k whose gate is closed (or max_iter)
@@ -233,7 +233,7 @@ __global__ void k_finalize(const int *flags, int world, int max_iter, int *kfina
 {
     if (threadIdx.x | blockIdx.x) return;
     int k = 0;
-    while (k < max_iter && gnn_gate_open(flags + (size_t)k * world, world)) ++k;
+    while (k < max_iter && gnn_gate_open(flags + (size_t)k * world * GNN_FLAG_WORDS, world)) ++k;
     *kfinal = k;
 }
 
@@ -320,7 +320,7 @@ __global__ void k_fill(int64_t count, float v, float *out)
 // ---------------------------------------------------------------------------------------------------------------------
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
-static int launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const int32_t *idx, const float *w,
+int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const int32_t *idx, const float *w,
                        const float *X, int width, int64_t ldx, float *out, int64_t ldo, const int *gate, int world)
 {
     if (n_rows == 0 || width == 0) return GNN_OK;
@@ -725,7 +725,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
         rc = dev_alloc(&l->state[b], (size_t)l->N_pad * Ds);
         if (!rc && hipMemset(l->state[b], 0, sizeof(float) * (size_t)l->N_pad * Ds) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "memset");
     }
-    if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world);
+    if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS);
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 1);
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
@@ -805,7 +805,7 @@ static int loop_allgather(gnn_loop *l, float *state_buf, int *flag_row)
     const size_t cnt = (size_t)l->shard_rows * l->Ds;
     NCCLCHK(g_rccl.GroupStart());
     if (state_buf) NCCLCHK(g_rccl.AllGather(state_buf + cnt * l->rank, state_buf, cnt, NCCL_FLOAT32, l->comm->nccl, l->stream));
-    if (flag_row) NCCLCHK(g_rccl.AllGather(flag_row + l->rank, flag_row, 1, NCCL_INT32, l->comm->nccl, l->stream));
+    if (flag_row) NCCLCHK(g_rccl.AllGather(flag_row + (size_t)l->rank * GNN_FLAG_WORDS, flag_row, GNN_FLAG_WORDS, NCCL_INT32, l->comm->nccl, l->stream));
     NCCLCHK(g_rccl.GroupEnd());
     return GNN_OK;
 }
@@ -814,7 +814,7 @@ static int unfused_iteration(gnn_loop *l, int k)
 {
     const gnn_graph *g = l->g;
     const int cur = k & 1, nxt = cur ^ 1, P = l->world;
-    const int *gate = l->flags + (size_t)k * P;
+    const int *gate = l->flags + (size_t)k * P * GNN_FLAG_WORDS;
     const float *own_cur = l->state[cur] + (size_t)g->row_begin * l->Ds;
     float *own_nxt = l->state[nxt] + (size_t)g->row_begin * l->Ds;
     // node_components (GNN.py:228): own state into columns [0, Ds) of the concat
@@ -822,7 +822,7 @@ static int unfused_iteration(gnn_loop *l, int k)
         HIPCHK(hipMemcpy2DAsync(l->inp, sizeof(float) * l->in_s, own_cur, sizeof(float) * l->Ds, sizeof(float) * l->Ds,
                                 (size_t)g->n_rows, hipMemcpyDeviceToDevice, l->stream));
     // aggregated_states (GNN.py:234) into columns [Ds + NLc, +Ds)
-    int rc = launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
+    int rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
                          l->inp + l->Ds + l->NLc, l->in_s, gate, P);
     if (rc) return rc;
     // net_state (GNN.py:240)
@@ -831,7 +831,7 @@ static int unfused_iteration(gnn_loop *l, int k)
     // condition for the next body (GNN.py:206-218)
     if (g->n_rows) {
         hipLaunchKernelGGL(k_check, cdiv(g->n_rows, 256), 256, 0, l->stream, g->n_rows, l->Ds, own_nxt, own_cur, l->thr,
-                           l->flags + (size_t)(k + 1) * P + l->rank, gate, P);
+                           l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS, gate, P);
         HIPCHK(hipGetLastError());
     }
     return GNN_OK;
@@ -860,7 +860,7 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     }
 
     HIPCHK(hipEventRecord(l->ev_total[0], st));
-    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P, st));
+    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P * GNN_FLAG_WORDS, st));
     float *own0 = l->state[0] + (size_t)g->row_begin * l->Ds;
     if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
         HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->row_begin * g->NL,
@@ -868,7 +868,7 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     // first condition: state vs ones (GNN.py:266, :271)
     if (g->n_rows) {
         hipLaunchKernelGGL(k_check, cdiv(g->n_rows, 256), 256, 0, st, g->n_rows, l->Ds, own0, (const float *)nullptr, l->thr,
-                           l->flags + l->rank, (const int *)nullptr, 1);
+                           l->flags + (size_t)l->rank * GNN_FLAG_WORDS, (const int *)nullptr, 1);
         HIPCHK(hipGetLastError());
     }
     if ((rc = loop_allgather(l, l->state[0], l->flags))) return rc;
@@ -876,10 +876,10 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     // loop-invariant aggregates (GNN.py:259, :263)
     if (!fused) {
         const int c_nodes = l->Ds, c_aggn = l->Ds + l->NLc + l->Ds, c_agga = c_aggn + l->NLc;
-        rc = launch_spmm(st, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL, l->inp + c_agga, l->in_s, nullptr, 1);
+        rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL, l->inp + c_agga, l->in_s, nullptr, 1);
         if (rc) return rc;
         if (l->D) {
-            rc = launch_spmm(st, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, l->inp + c_aggn, l->in_s, nullptr, 1);
+            rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, l->inp + c_aggn, l->in_s, nullptr, 1);
             if (rc) return rc;
             if (g->n_rows)
                 HIPCHK(hipMemcpy2DAsync(l->inp + c_nodes, sizeof(float) * l->in_s, g->nodes + (size_t)g->row_begin * g->NL, sizeof(float) * g->NL,
@@ -892,7 +892,7 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
         rc = fused ? gnn_fused_iteration(l, k) : unfused_iteration(l, k);
         if (rc) return rc;
         if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k + 1], st));
-        if ((rc = loop_allgather(l, l->state[(k & 1) ^ 1], l->flags + (size_t)(k + 1) * P))) return rc;
+        if ((rc = loop_allgather(l, l->state[(k & 1) ^ 1], l->flags + (size_t)(k + 1) * P * GNN_FLAG_WORDS))) return rc;
     }
     hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, P, l->max_iter, l->kfinal_dev);
     HIPCHK(hipGetLastError());

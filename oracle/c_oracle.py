@@ -15,6 +15,19 @@ ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 's
 BN_EPS = 1e-3
 
 
+def default_threads() -> int:
+    """Threads the C oracle may use: the CPU share of this process (affinity, cgroup quota), capped at 64."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get('GNN_ORACLE_THREADS')
+    return int(env) if env else max(1, min(n, 64))
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, 'gnn_oracle.c')
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -35,6 +48,7 @@ def lib():
         _lib.orc_expf.argtypes = [C.c_float]
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_loop.restype = C.c_int
+        _lib.orc_set_threads(C.c_int(default_threads()))
     return _lib
 
 
@@ -105,6 +119,7 @@ def readout(nodegraph, out_nodes):
 def loop_node(g: dict, net_state: dict, net_output: dict, state_vect_dim: int, max_iteration: int, threshold: float,
               state0=None, n_threads: int = 0, want_out: bool = True):
     """Same contract as gnn_oracle.loop_node, evaluated by the C restatement (fixed fp evaluation order)."""
+    n_threads = n_threads or default_threads()
     l = lib()
     nodes = np.ascontiguousarray(g['nodes'], dtype=np.float32)
     arcl = np.ascontiguousarray(np.asarray(g['arcs'], dtype=np.float32)[:, 2:])

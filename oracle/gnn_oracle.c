@@ -293,6 +293,15 @@ void orc_readout(int64_t N, int G, int T, const float *nodegraph, const float *o
         }
 }
 
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
