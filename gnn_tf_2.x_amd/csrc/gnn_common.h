@@ -26,13 +26,13 @@ int gnn_fail(int code, const char *fmt, ...);
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gnn_expf(float x)
 {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -87.33654022216797f) return 0.0f;
-    float n = __builtin_rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, x);
+    // branch-free form of oracle/gnn_oracle.c:orc_expf: same operations on the in-range path, selects for the rest.
+    // ldexpf(y, n) == (y * 2^(n/2)) * 2^(n - n/2) bit for bit (both scale exactly and round once, on underflow only).
+    const float xc = __builtin_fminf(__builtin_fmaxf(x, -87.33654022216797f), 88.72283935546875f);
+    const float n = __builtin_rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, xc);
     r = __builtin_fmaf(n, 2.12194440e-4f, r);
-    float z = r * r;
+    const float z = r * r;
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
     p = __builtin_fmaf(p, r, 8.3334519073e-3f);
@@ -41,10 +41,10 @@ __device__ __forceinline__ float gnn_expf(float x)
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
     float y = __builtin_fmaf(p, z, r);
     y = y + 1.0f;
-    int ni = (int)n;
-    int n1 = ni / 2, n2 = ni - n1;
-    float s1 = __uint_as_float((uint32_t)(n1 + 127) << 23), s2 = __uint_as_float((uint32_t)(n2 + 127) << 23);
-    return (y * s1) * s2;
+    float e = __builtin_ldexpf(y, (int)n);
+    e = x > 88.72283935546875f ? __builtin_inff() : e;
+    e = x < -87.33654022216797f ? 0.0f : e;
+    return x != x ? x : e;
 }
 
 __device__ __forceinline__ float gnn_act(float v, int act)

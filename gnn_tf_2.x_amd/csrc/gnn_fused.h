@@ -1,0 +1,33 @@
+// Host/device interface of the fused iteration kernel (gnn_fused_kernel.h).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int GNN_FUSED_MAXL = 3;
+
+struct GnnFusedArgs {
+    // graph
+    int64_t n_rows, row_begin;
+    const int32_t *indptr, *adj_src;
+    const float *adj_w;
+    const float *inv;        // [n_rows, IW] = [nodes | aggregated nodes | aggregated arcs] (label columns of the concat)
+    // state
+    const float *state_cur;  // [N_pad, Ds] all nodes
+    float *state_nxt;        // owned rows
+    // shapes
+    int Ds, NLc, AL, IW, in_s, KP, lpr, lpr_log2, vec, kk0;
+    // layers: packed weights [kk][lane][tiles of the layer], biases padded to whole tiles
+    const float *Wp[GNN_FUSED_MAXL];
+    const float *bias[GNN_FUSED_MAXL];
+    const float *bn_scale, *bn_shift;   // padded to whole tiles, or nullptr
+    // control
+    float thr;
+    const int *gate;
+    int *flag_out;
+    int world;
+};
+
+// one per translation unit gnn_fused_l{1,2,3}.hip; false = no instantiation for (act, nt, ntl)
+bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_l2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_l3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
