@@ -99,6 +99,7 @@ def main():
     ap.add_argument('--arcs-per-node', type=float, default=10.0)
     ap.add_argument('--max-iter', type=int, default=30)
     ap.add_argument('--impl', type=int, default=1, help='1: fused kernel (default), 0: one kernel per TF op')
+    ap.add_argument('--act', default='selu', help='net_state activation (experiments; the BASELINE config is selu)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=3)
     args = ap.parse_args()
@@ -116,7 +117,7 @@ def main():
     s = utils.syntheticGraph(args.nodes, args.arcs_per_node, nl, al, t, seed=20261003)
     n, e = s['n_nodes'], s['n_arcs']
     rng = np.random.default_rng(20261003)
-    st = make_net(rng, al + 2 * (nl + d), [128, 128, d], 'selu')
+    st = make_net(rng, al + 2 * (nl + d), [128, 128, d], args.act)
     ou = make_net(rng, nl + d, [t], 'softmax')
     state0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
 

@@ -146,6 +146,7 @@ struct gnn_loop {
     float *tmp[2] = {nullptr, nullptr};     // unfused: layer activations
     float *feats = nullptr, *out = nullptr, *otmp[2] = {nullptr, nullptr};
     int *flags = nullptr;                   // [(max_iter+2), world, GNN_FLAG_WORDS]
+    int *tile_ctr = nullptr;                // fused path: one tile counter per iteration [max_iter + 1]
     int *kfinal_dev = nullptr, *kfinal_host = nullptr;
     int kfinal = -1;
     bool have_state0 = false, ran = false;

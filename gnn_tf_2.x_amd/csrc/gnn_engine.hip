@@ -727,6 +727,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS);
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 1);
+    if (!rc) rc = dev_alloc(&l->tile_ctr, (size_t)max_iter + 1);
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
     if (!rc) rc = dev_alloc(&l->out, (size_t)g->n_masked * l->T);
@@ -861,6 +862,7 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
 
     HIPCHK(hipEventRecord(l->ev_total[0], st));
     HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P * GNN_FLAG_WORDS, st));
+    HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * (size_t)(l->max_iter + 1), st));
     float *own0 = l->state[0] + (size_t)g->row_begin * l->Ds;
     if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
         HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->row_begin * g->NL,
@@ -1003,7 +1005,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     if (!l) return GNN_OK;
     (void)hipSetDevice(l->device);
     for (int b = 0; b < 2; ++b) { (void)hipFree(l->state[b]); (void)hipFree(l->tmp[b]); (void)hipFree(l->otmp[b]); }
-    (void)hipFree(l->inp); (void)hipFree(l->inv); (void)hipFree(l->state_init); (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->flags); (void)hipFree(l->kfinal_dev);
+    (void)hipFree(l->inp); (void)hipFree(l->inv); (void)hipFree(l->state_init); (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->flags); (void)hipFree(l->kfinal_dev); (void)hipFree(l->tile_ctr);
     if (l->kfinal_host) (void)hipHostFree(l->kfinal_host);
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);

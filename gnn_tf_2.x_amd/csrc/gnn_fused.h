@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 constexpr int GNN_FUSED_MAXL = 3;
+constexpr int GNN_FUSED_WAVES = 8;                 // waves per (persistent) workgroup; w and w + 4 share a SIMD
+constexpr int GNN_FUSED_THREADS = 64 * GNN_FUSED_WAVES;
 
 struct GnnFusedArgs {
     // graph
@@ -25,6 +27,11 @@ struct GnnFusedArgs {
     const int *gate;
     int *flag_out;
     int world;
+    int *tile_ctr;           // device-wide tile counter of this iteration (zeroed at the start of gnn_loop_run)
+    int wstride;             // 1 normally; 0 (GNN_FUSED_DEBUG=1, timing experiments only) makes every K-step re-read step 0
+    int stagger;             // s_sleep(127) rounds the second half of the waves waits before its first tile
+    // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
+    unsigned long long *stamps;
 };
 
 // one per translation unit gnn_fused_l{1,2,3}.hip; false = no instantiation for (act, nt, ntl)

@@ -1,5 +1,8 @@
 // Host side of the fused iteration kernel (device code: gnn_fused_kernel.h): which nets it covers, the packed weight
 // image, the loop-invariant label block, and the per-iteration launch.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -9,8 +12,8 @@
 namespace {
 
 constexpr int MAXL = GNN_FUSED_MAXL;
-constexpr int K_GROUP = 8;      // layer-0 K-steps are consumed in pipelined groups of 2 x 4 (layer_from_lds)
-constexpr int K_SLACK = 4;      // zero K-steps after the layer-0 block: the pipeline prefetches one group past the end
+constexpr int K_GROUP = 12;     // layer-0 K-steps are consumed in pipelined groups of 3 x 4 (layer_from_lds)
+constexpr int K_SLACK = 8;      // zero K-steps after the layer-0 block: the pipeline prefetches two groups past the end
 
 struct FusedPlan {
     int layers = 0, NT = 0, NTL = 0, KP = 0, kk0 = 0, act = 0;
@@ -55,7 +58,11 @@ bool make_plan(const gnn_mlp *m, FusedPlan &p)
     return true;
 }
 
-size_t lds_bytes(const FusedPlan &p) { return (size_t)4 * 32 * p.KP * sizeof(float) + 64; }
+// GNN_FUSED_WAVES wave tiles [32][KP], 128 B of slack (the layer-0 pipeline reads two groups past the last tile), GNN_FUSED_WAVES x 36 row pointers
+size_t lds_bytes(const FusedPlan &p)
+{
+    return (size_t)GNN_FUSED_WAVES * 32 * p.KP * sizeof(float) + 128 + GNN_FUSED_WAVES * 36 * sizeof(int);
+}
 
 }   // namespace
 
@@ -109,7 +116,7 @@ bool gnn_fused_supported(const gnn_loop *l)
 {
     FusedPlan p;
     if (!l->st->packed || !make_plan(l->st, p)) return false;
-    if (lds_bytes(p) > 80 * 1024) return false;                             // two workgroups per CU
+    if (lds_bytes(p) > 160 * 1024) return false;                            // one 8-wave workgroup per CU
     const int Ds = l->Ds;
     if (!((Ds % 4 == 0 && Ds <= 256) || Ds <= 64)) return false;           // one column chunk per lane in the gather
     return l->g->n_rows > 0;
@@ -154,7 +161,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.Ds = l->Ds; a.NLc = l->NLc; a.AL = g->AL; a.IW = 2 * l->NLc + g->AL; a.in_s = l->in_s; a.KP = p.KP; a.kk0 = p.kk0;
     a.vec = (l->Ds % 4 == 0) ? 4 : 1;
     int lpr = 1, lg = 0;
-    while (lpr * a.vec < l->Ds && lpr < 64) { lpr <<= 1; ++lg; }
+    while ((lpr * a.vec < l->Ds || lpr < 2) && lpr < 64) { lpr <<= 1; ++lg; }
     a.lpr = lpr; a.lpr_log2 = lg;
     for (int i = 0; i < p.layers; ++i) {
         a.Wp[i] = m->packed + p.w_off[i];
@@ -166,13 +173,39 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.gate = l->flags + (size_t)k * P * GNN_FLAG_WORDS;
     a.flag_out = l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS;
     a.world = P;
-    const unsigned grid = (unsigned)((g->n_rows + 127) / 128);
+    a.stamps = nullptr;
+    static const int debug = getenv("GNN_FUSED_DEBUG") ? atoi(getenv("GNN_FUSED_DEBUG")) : 0;   // timing experiments only
+    a.wstride = (debug & 1) ? 0 : 1;
+    static const char *stamp_file = getenv("GNN_FUSED_STAMPS");       // diagnostics: dump per-wave phase stamps of body 1
+    static unsigned long long *stamp_buf = nullptr;
+    const size_t n_tiles = (size_t)((g->n_rows + 31) / 32);
+    const size_t n_waves = n_tiles;
+    if (stamp_file && k == 1) {
+        if (!stamp_buf) HIPCHK(hipMalloc((void **)&stamp_buf, n_waves * 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(stamp_buf, 0, n_waves * 8 * sizeof(unsigned long long), l->stream));
+        a.stamps = stamp_buf;
+    }
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, l->device));
+        n_cu = std::max(1, prop.multiProcessorCount);
+    }
+    const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, (n_tiles + GNN_FUSED_WAVES - 1) / GNN_FUSED_WAVES);
+    a.tile_ctr = l->tile_ctr + k;
+    a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? 5 : 0;   // only when every wave has several tiles to run
     const size_t lds = lds_bytes(p);
     bool ok = false;
     if (p.layers == 1) ok = gnn_fused_launch_l1(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     else if (p.layers == 2) ok = gnn_fused_launch_l2(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     else ok = gnn_fused_launch_l3(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);
+    if (a.stamps) {
+        std::vector<unsigned long long> host(n_waves * 8);
+        HIPCHK(hipStreamSynchronize(l->stream));
+        HIPCHK(hipMemcpy(host.data(), stamp_buf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(stamp_file, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+    }
     HIPCHK(hipGetLastError());
     return GNN_OK;
 }

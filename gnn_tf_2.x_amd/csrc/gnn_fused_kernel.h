@@ -30,6 +30,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace gnn_fused_dev {
 
+// The tile loop launders its pointers through empty asm statements (see k_fused); that hides from the compiler that they
+// are global-memory pointers, and it would fall back to flat_load/flat_store (which also tie up the LDS counter).  All
+// memory accesses below therefore go through explicit address_space(1) pointers.
+#define GNN_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ const GNN_GLOBAL T *gptr(const T *p) { return (const GNN_GLOBAL T *)p; }
+template <class T>
+__device__ __forceinline__ GNN_GLOBAL T *gptr_w(T *p) { return (GNN_GLOBAL T *)p; }
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4f gload4(const float *p) { return *(const GNN_GLOBAL v4f *)p; }
+__device__ __forceinline__ v2f gload2(const float *p) { return *(const GNN_GLOBAL v2f *)p; }
+__device__ __forceinline__ float gload1(const float *p) { return *(const GNN_GLOBAL float *)p; }
+__device__ __forceinline__ int gload1(const int *p) { return *(const GNN_GLOBAL int *)p; }
+
 __device__ __forceinline__ float shfl_f(float v, int src_lane)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -56,20 +71,42 @@ template <int N>
 __device__ __forceinline__ void load_w(const float *p, float (&w)[N])
 {
     if constexpr (N == 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(p);
+        const v4f t = gload4(p);
         w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
     } else if constexpr (N == 2) {
-        const float2 t = *reinterpret_cast<const float2 *>(p);
+        const v2f t = gload2(p);
         w[0] = t.x; w[1] = t.y;
     } else {
-        w[0] = p[0];
+        w[0] = gload1(p);
     }
 }
 
 template <int ACT>
 __device__ __forceinline__ float act_t(float v)
 {
-    return gnn_act(v, ACT);     // ACT is a compile-time constant: the switch folds
+    if constexpr (ACT == GNN_ACT_SELU) {
+        // gnn_act(v, SELU) with the parts of gnn_expf that cannot influence the result removed: exp is only used for
+        // v <= 0 (no overflow side), NaN propagates through the arithmetic, and the underflow select stays.  On every
+        // input this returns the same bits as the generic form.
+        const float n = __builtin_rintf(v * 1.44269504088896341f);
+        float r = __builtin_fmaf(n, -0.693359375f, v);
+        r = __builtin_fmaf(n, 2.12194440e-4f, r);
+        const float z = r * r;
+        float p = 1.9875691500e-4f;
+        p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+        p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+        p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+        p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+        p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+        float y = __builtin_fmaf(p, z, r);
+        y = y + 1.0f;
+        float e = __builtin_ldexpf(y, (int)n);
+        e = v < -87.33654022216797f ? 0.0f : e;
+        const float neg = 1.6732632423543772f * (e - 1.0f);
+        return 1.0507009873554805f * (v > 0.0f ? v : neg);
+    } else {
+        return gnn_act(v, ACT);     // ACT is a compile-time constant: the switch folds
+    }
 }
 
 // bias + activation (+ BatchNormalization when BN) on one accumulator tile; feature of register r on this lane:
@@ -81,11 +118,11 @@ __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, cons
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int f0 = 32 * jt + 8 * q + 4 * half;
-        const float4 b = *reinterpret_cast<const float4 *>(bias + f0);
+        const v4f b = gload4(bias + f0);
         const float bb[4] = {b.x, b.y, b.z, b.w};
         float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
         if (BN) {
-            const float4 s4 = *reinterpret_cast<const float4 *>(bn_scale + f0), h4 = *reinterpret_cast<const float4 *>(bn_shift + f0);
+            const v4f s4 = gload4(bn_scale + f0), h4 = gload4(bn_shift + f0);
             sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
             sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
         }
@@ -99,55 +136,396 @@ __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, cons
     }
 }
 
-// Dense layer whose input is the LDS tile X (layer 0).  KK (multiple of 8) K-steps, software pipelined in groups of 4:
-// the weight loads and LDS reads of group g+1 are issued before the MFMAs of group g.
+// Dense layer whose input is the LDS tile X (layer 0).  KK (multiple of 12) K-steps in groups of 4 with three register
+// sets: the weight loads / LDS reads of group g+2 are issued before the MFMAs of group g, i.e. 8 K-steps (2048 matrix
+// cycles) ahead.  Reads past the end land in the zero slack of the packed image / LDS (see gnn_fused.hip) and are unused.
 template <int NO>
-__device__ __forceinline__ void layer_from_lds(const float *xb, const float *wp, int kk_total, f32x16 (&acc)[NO])
+__device__ __forceinline__ void layer_from_lds(const float *xb, const float *wp, int kk_total, f32x16 (&acc)[NO], int wstride)
 {
     constexpr int PF = 4;
-    float wa[PF][NO], wb[PF][NO], ba[PF], bb[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) { load_w<NO>(wp + (size_t)u * 64 * NO, wa[u]); ba[u] = xb[2 * u]; }
-    for (int kk = 0; kk < kk_total; kk += 2 * PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { load_w<NO>(wp + (size_t)(kk + PF + u) * 64 * NO, wb[u]); bb[u] = xb[2 * (kk + PF + u)]; }
-        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMAs it overlaps with
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-#pragma unroll
-            for (int jt = 0; jt < NO; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u][jt], ba[u], acc[jt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        // group kk + 2 PF (reads past the end land in the zero padding of the packed image / LDS tile: see gnn_fused.hip)
-#pragma unroll
-        for (int u = 0; u < PF; ++u) { load_w<NO>(wp + (size_t)(kk + 2 * PF + u) * 64 * NO, wa[u]); ba[u] = xb[2 * (kk + 2 * PF + u)]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-#pragma unroll
-            for (int jt = 0; jt < NO; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[u][jt], bb[u], acc[jt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    float wa[PF][NO], wb[PF][NO], wc[PF][NO], ba[PF], bb[PF], bc[PF];
+#define GNN_L0_LOAD(W, B, K0)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < PF; ++u) {                                                \
+        load_w<NO>(wp + (size_t)((K0) + u) * 64 * NO * wstride, W[u]);                                        \
+        B[u] = xb[2 * ((K0) + u)];                                                                  \
+    }                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);
+#define GNN_L0_MFMA(W, B)                                                                           \
+    _Pragma("unroll") for (int u = 0; u < PF; ++u)                                                  \
+        _Pragma("unroll") for (int jt = 0; jt < NO; ++jt)                                           \
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(W[u][jt], B[u], acc[jt], 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);
+    GNN_L0_LOAD(wa, ba, 0)
+    GNN_L0_LOAD(wb, bb, PF)
+    for (int kk = 0; kk < kk_total; kk += 3 * PF) {
+        GNN_L0_LOAD(wc, bc, kk + 2 * PF)
+        GNN_L0_MFMA(wa, ba)
+        GNN_L0_LOAD(wa, ba, kk + 3 * PF)
+        GNN_L0_MFMA(wb, bb)
+        GNN_L0_LOAD(wb, bb, kk + 4 * PF)
+        GNN_L0_MFMA(wc, bc)
     }
+#undef GNN_L0_LOAD
+#undef GNN_L0_MFMA
 }
 
-// Dense layer whose input sits in registers as B operands (hin, after acc_to_operand): 16 NI K-steps, fully unrolled,
-// weight loads issued DEPTH steps ahead of their MFMAs.
-template <int NI, int NO>
-__device__ __forceinline__ void layer_from_regs(const f32x16 (&hin)[NI], f32x16 (&acc)[NO], const float *wp)
+// Activation split into four stages so that it can be issued in the shadow of consecutive MFMAs (an MFMA occupies the
+// matrix pipe for 64 cycles but the wave's issue port only briefly; the wave issues in order, so VALU work has to sit
+// BETWEEN the MFMAs to overlap with them).  The concatenation of the stages is exactly act_t<ACT>(v + bias).
+template <int ACT>
+struct ActPipe {
+    float t, n, r, z, p, e;
+    __device__ __forceinline__ void s0(float v, float bias)
+    {
+        t = v + bias;
+        if constexpr (ACT == GNN_ACT_SELU) {
+            n = __builtin_rintf(t * 1.44269504088896341f);
+            r = __builtin_fmaf(n, -0.693359375f, t);
+            r = __builtin_fmaf(n, 2.12194440e-4f, r);
+            z = r * r;
+        }
+    }
+    __device__ __forceinline__ void s1()
+    {
+        if constexpr (ACT == GNN_ACT_SELU) {
+            p = 1.9875691500e-4f;
+            p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+            p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+            p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+            p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+            p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+        }
+    }
+    __device__ __forceinline__ void s2()
+    {
+        if constexpr (ACT == GNN_ACT_SELU) {
+            float y = __builtin_fmaf(p, z, r);
+            y = y + 1.0f;
+            e = __builtin_ldexpf(y, (int)n);
+        }
+    }
+    __device__ __forceinline__ float s3()
+    {
+        if constexpr (ACT == GNN_ACT_SELU) {
+            e = t < -87.33654022216797f ? 0.0f : e;
+            const float neg = 1.6732632423543772f * (e - 1.0f);
+            return 1.0507009873554805f * (t > 0.0f ? t : neg);
+        } else {
+            return gnn_act(t, ACT);
+        }
+    }
+};
+
+// Dense layer whose input is the RAW accumulator of the previous layer (hin).  The previous layer's epilogue (bias +
+// activation, then the half-wave exchange that turns an accumulator tile into B operands) is applied here and
+// software-pipelined against this layer's MFMAs in plain program order: K-step ss of input tile ti issues NO MFMAs, and
+// BETWEEN them (the wave issues in order, so that is the only place where VALU work overlaps the matrix pipe) sit the
+// stages of the epilogue of element ss of input tile ti + 1 (ActPipe; on odd ss also the exchange of the pair).  Only the
+// epilogue of tile 0 is exposed.  16 NI K-steps, fully unrolled; weight loads are issued DEPTH steps ahead of their MFMAs; a sched_barrier after
+// every step pins this order.
+template <int NI, int NO, int ACT>
+__device__ __forceinline__ void layer_from_regs(f32x16 (&hin)[NI], const float *bias_prev, int half, f32x16 (&acc)[NO],
+                                                const float *wp, int wstride)
 {
     constexpr int STEPS = 16 * NI, DEPTH = 8;
     float w[STEPS][NO];
 #pragma unroll
-    for (int s = 0; s < DEPTH; ++s) load_w<NO>(wp + (size_t)s * 64 * NO, w[s]);
+    for (int s = 0; s < DEPTH; ++s) load_w<NO>(wp + (size_t)s * 64 * NO * wstride, w[s]);
+    tile_epilogue<ACT, false>(hin[0], bias_prev, nullptr, nullptr, 0, half);
+    acc_to_operand(hin[0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-        if (s + DEPTH < STEPS) load_w<NO>(wp + (size_t)(s + DEPTH) * 64 * NO, w[s + DEPTH]);
-        __builtin_amdgcn_sched_barrier(0);      // the load stays DEPTH steps ahead of its MFMAs
-        const int ti = s >> 4, ss = s & 15;
-        const int reg = 4 * (ss >> 2) + ((ss & 3) == 1 ? 2 : (ss & 3) == 2 ? 1 : (ss & 3));
-        const float b = hin[ti][reg];
+    for (int ti = 0; ti < NI; ++ti) {
+        float nb[16];                                   // biases of the 16 features this lane holds of tile ti + 1
+        if (ti + 1 < NI) {
 #pragma unroll
-        for (int jt = 0; jt < NO; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][jt], b, acc[jt], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const v4f b4 = gload4(bias_prev + 32 * (ti + 1) + 8 * q + 4 * half);
+                nb[4 * q] = b4.x; nb[4 * q + 1] = b4.y; nb[4 * q + 2] = b4.z; nb[4 * q + 3] = b4.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ss = 0; ss < 16; ++ss) {
+            const int s = 16 * ti + ss;
+            if (s + DEPTH < STEPS) load_w<NO>(wp + (size_t)(s + DEPTH) * 64 * NO * wstride, w[s + DEPTH]);
+            const int reg = 4 * (ss >> 2) + ((ss & 3) == 1 ? 2 : (ss & 3) == 2 ? 1 : (ss & 3));
+            const float b = hin[ti][reg];
+            ActPipe<ACT> ap;
+            const bool epi = ti + 1 < NI;
+#pragma unroll
+            for (int jt = 0; jt < NO; ++jt) {
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][jt], b, acc[jt], 0, 0, 0);
+                if (epi) {      // stage(s) of the epilogue of element ss of tile ti + 1, in the shadow of this MFMA
+                    constexpr int SPM = 4 / NO;                      // stages per MFMA: NO = 4 -> 1, 2 -> 2, 1 -> 4
+#pragma unroll
+                    for (int st = jt * SPM; st < (jt + 1) * SPM; ++st) {
+                        if (st == 0) ap.s0(hin[ti + 1][ss], nb[ss]);
+                        if (st == 1) ap.s1();
+                        if (st == 2) ap.s2();
+                        if (st == 3) {
+                            hin[ti + 1][ss] = ap.s3();
+                            if (ss & 1) {
+                                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(hin[ti + 1][ss - 1]),
+                                                                           __float_as_uint(hin[ti + 1][ss]), false, false);
+                                hin[ti + 1][ss - 1] = __uint_as_float(sw[0]);
+                                hin[ti + 1][ss] = __uint_as_float(sw[1]);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tile load + gather.  X[32][KP] columns: [state | nodes? | aggregated state | aggregated nodes? | aggregated arcs | 0 pad]
+// ---------------------------------------------------------------------------------------------------------------------
+
+// label columns [nodes | agg nodes | agg arcs] of inv[n_rows][IW] -> columns Ds.., 2Ds+NLc.., 2Ds+2NLc..
+__device__ __forceinline__ int label_col(int c, int Ds, int NLc)
+{
+    return c < NLc ? Ds + c : (c < 2 * NLc ? 2 * Ds + NLc + (c - NLc) : 2 * Ds + 2 * NLc + (c - 2 * NLc));
+}
+
+__device__ __forceinline__ void zero_pad_columns(const GnnFusedArgs &a, float *X, int lane, int KP)
+{
+    const int padw = KP - a.in_s;
+    for (int t = lane; t < 32 * padw; t += 64) {
+        const int i = t / padw, c = t - i * padw;
+        X[i * KP + a.in_s + c] = 0.0f;
+    }
+}
+
+// Generic shapes (any Ds, partial tiles).  Correct for everything, tuned for nothing: small graphs are launch-bound.
+__device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
+                                               int nvalid, int KP, int c_aggs)
+{
+    const int Ds = a.Ds, NLc = a.NLc;
+    zero_pad_columns(a, X, lane, KP);
+    if (nvalid < 32)
+        for (int t = lane; t < (32 - nvalid) * a.in_s; t += 64) {
+            const int i = nvalid + t / a.in_s, c = t % a.in_s;
+            X[i * KP + c] = 0.0f;
+        }
+    {   // own state rows (contiguous in HBM) into columns [0, Ds)
+        const float *src = a.state_cur + (a.row_begin + i0) * Ds;
+        const int total = nvalid * Ds;
+        for (int t = lane; t < total; t += 64) {
+            const int i = t / Ds, f = t - i * Ds;
+            X[i * KP + f] = gload1(src + t);
+        }
+    }
+    if (a.IW > 0) {
+        const float *src = a.inv + i0 * a.IW;
+        const int total = nvalid * a.IW;
+        for (int t = lane; t < total; t += 64) {
+            const int i = t / a.IW, c = t - i * a.IW;
+            X[i * KP + label_col(c, Ds, NLc)] = gload1(src + t);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // gather: groups of lpr lanes, one node per group per pass, one column chunk per lane (lpr * vec >= Ds)
+    const int lpr = a.lpr, gl = lane & (lpr - 1), grp = lane >> a.lpr_log2, groups = 64 >> a.lpr_log2;
+    const bool colok = gl * a.vec < Ds;
+    const int c0 = colok ? gl * a.vec : 0;
+    for (int pass = 0; pass * groups < 32; ++pass) {
+        const int i = pass * groups + grp;                 // < 32 because groups divides 32 (lpr >= 2)
+        const int beg = ipt[i], end = ipt[i + 1];          // rows past nvalid: beg == end
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = beg; e < end; ++e) {
+            const float w = gload1(a.adj_w + e);
+            const float *xp = a.state_cur + (int64_t)gload1(a.adj_src + e) * Ds + c0;
+            if (a.vec == 4) {
+                const v4f v = gload4(xp);
+                acc[0] = __builtin_fmaf(w, v.x, acc[0]); acc[1] = __builtin_fmaf(w, v.y, acc[1]);
+                acc[2] = __builtin_fmaf(w, v.z, acc[2]); acc[3] = __builtin_fmaf(w, v.w, acc[3]);
+            } else {
+                acc[0] = __builtin_fmaf(w, gload1(xp), acc[0]);
+            }
+        }
+        if (i < nvalid && colok) {
+            float *x = X + i * KP + c_aggs + c0;
+            x[0] = acc[0];
+            if (a.vec == 4) { x[1] = acc[1]; x[2] = acc[2]; x[3] = acc[3]; }
+        }
+    }
+}
+
+// Ds == 64, full tile.  Lane group g (16 lanes, 16 B per lane = one 256 B state row per group and instruction) owns the
+// 8 consecutive nodes 8g..8g+7 and walks their contiguous CSR entries in batches of GB: ids/weights of a batch are fetched
+// coalesced by the group (and those of the next batch prefetched), the GB neighbour rows are all requested before the
+// first is consumed (GB x 4 groups x 256 B = 16 KiB in flight per wave), and the fmaf chain runs in stored order,
+// flushing to LDS at every row boundary.
+__device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
+                                                 int KP, int c_aggs)
+{
+    constexpr int GB = 16, Ds = 64;
+    const int gl = lane & 15, grp = lane >> 4, gbase = lane & 48;
+    // own state rows: 8 x 16 B per lane requested now, written to LDS after the gather (their latency hides behind it)
+    v4f own[8];
+    {
+        const float *src = a.state_cur + (a.row_begin + i0) * Ds + lane * 4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) own[u] = gload4(src + u * 256);
+    }
+    float lab[4];
+    const int IW = a.IW, nlab = 32 * IW;
+    {
+        const float *src = a.inv + i0 * IW;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lab[u] = (lane + 64 * u < nlab) ? gload1(src + lane + 64 * u) : 0.0f;
+    }
+    zero_pad_columns(a, X, lane, KP);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                   // ipt visible to the whole wave
+
+    int node = grp * 8;
+    const int node_end = node + 8;
+    const int e_begin = ipt[node], e_end = ipt[node_end];
+    int next_end = ipt[node + 1];
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    const float *sc = a.state_cur + gl * 4;
+    float *xo = X + c_aggs + gl * 4;
+#define GNN_ROW_BOUNDARY(e)                                                                     \
+    while ((e) >= next_end) {                                                                   \
+        float *xr = xo + node * KP;                                                             \
+        xr[0] = acc0; xr[1] = acc1; xr[2] = acc2; xr[3] = acc3;                                 \
+        acc0 = acc1 = acc2 = acc3 = 0.0f;                                                       \
+        ++node;                                                                                 \
+        next_end = ipt[node + 1];                                                               \
+    }
+    int my_src = 0;
+    float my_w = 0.0f;
+    if (e_begin + gl < e_end) { my_src = gload1(a.adj_src + e_begin + gl); my_w = gload1(a.adj_w + e_begin + gl); }
+    int base = e_begin;
+    for (; base + GB <= e_end; base += GB) {                                 // full batches: no guards
+        float w[GB];
+        v4f x[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int s_ = shfl_i(my_src, gbase + u);
+            w[u] = shfl_f(my_w, gbase + u);
+            x[u] = gload4(sc + (int64_t)s_ * Ds);
+        }
+        const int nb = base + GB + gl;                                       // ids / weights of the next batch
+        my_src = 0; my_w = 0.0f;
+        if (nb < e_end) { my_src = gload1(a.adj_src + nb); my_w = gload1(a.adj_w + nb); }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            GNN_ROW_BOUNDARY(base + u)
+            acc0 = __builtin_fmaf(w[u], x[u].x, acc0); acc1 = __builtin_fmaf(w[u], x[u].y, acc1);
+            acc2 = __builtin_fmaf(w[u], x[u].z, acc2); acc3 = __builtin_fmaf(w[u], x[u].w, acc3);
+        }
+    }
+    {                                                                        // tail batch: cnt in [0, GB)
+        const int cnt = e_end - base;
+        float w[GB];
+        v4f x[GB];
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            const int uu = u < cnt ? u : 0;                                  // clamp: re-reads entry 0, result unused
+            const int s_ = shfl_i(my_src, gbase + uu);                       // (cnt == 0: lane value 0 = row 0, unused)
+            w[u] = shfl_f(my_w, gbase + uu);
+            x[u] = gload4(sc + (int64_t)s_ * Ds);
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            if (u < cnt) {
+                GNN_ROW_BOUNDARY(base + u)
+                acc0 = __builtin_fmaf(w[u], x[u].x, acc0); acc1 = __builtin_fmaf(w[u], x[u].y, acc1);
+                acc2 = __builtin_fmaf(w[u], x[u].z, acc2); acc3 = __builtin_fmaf(w[u], x[u].w, acc3);
+            }
+        }
+    }
+#undef GNN_ROW_BOUNDARY
+    for (; node < node_end; ++node) {                                        // last row with entries, then empty rows
+        float *xr = xo + node * KP;
+        xr[0] = acc0; xr[1] = acc1; xr[2] = acc2; xr[3] = acc3;
+        acc0 = acc1 = acc2 = acc3 = 0.0f;
+    }
+    // own state and label columns into the tile
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float *x = X + (4 * u + (lane >> 4)) * KP + (lane & 15) * 4;         // flat element 256 u + 4 lane = row 4u + lane/16
+        x[0] = own[u].x; x[1] = own[u].y; x[2] = own[u].z; x[3] = own[u].w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = lane + 64 * u;
+        if (t < nlab) {
+            const int i = t / IW, c = t - i * IW;
+            X[i * KP + label_col(c, Ds, a.NLc)] = lab[u];
+        }
+    }
+    if (nlab > 256)                                                          // wide label blocks: the rest, plainly
+        for (int t = 256 + lane; t < nlab; t += 64) {
+            const int i = t / IW, c = t - i * IW;
+            X[i * KP + label_col(c, Ds, a.NLc)] = gload1(a.inv + i0 * IW + t);
+        }
+}
+
+// condition() for the next body + coalesced store of the new rows.  New state sits in columns [c_aggs, c_aggs + Ds).
+// lanes 0..31 sum (new - old)^2, lanes 32..63 sum old^2, ascending feature order, unfused (oracle order).
+__device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int nvalid, int KP,
+                                                 int c_aggs)
+{
+    const int Ds = a.Ds, half = lane >> 5;
+    const float *xo = X + (lane & 31) * KP, *xn = xo + c_aggs;
+    float s_ = 0.0f;
+    for (int f = 0; f < Ds; ++f) {
+        const float o = xo[f];
+        const float d = half ? o : (xn[f] - o);
+        const float dd = d * d;
+        s_ = s_ + dd;
+    }
+    const float root = __fsqrt_rn(s_);
+    const float nrm = shfl_f(root, (lane & 31) + 32);
+    const float rhs = a.thr * nrm;
+    const int moved = (half == 0) && ((lane & 31) < nvalid) && (root > rhs);
+    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    float *dst = a.state_nxt + i0 * Ds;
+    const int total = nvalid * Ds;
+    for (int t = lane; t < total; t += 64) {
+        const int i = t / Ds, f = t - i * Ds;
+        gptr_w(dst)[t] = X[i * KP + c_aggs + f];
+    }
+}
+
+__device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int KP, int c_aggs)
+{
+    constexpr int Ds = 64;
+    const int half = lane >> 5;
+    const float *xo = X + (lane & 31) * KP, *xn = xo + c_aggs;
+    float s_ = 0.0f;
+#pragma unroll
+    for (int f = 0; f < Ds; f += 16) {
+        float o[16], nw[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { o[u] = xo[f + u]; nw[u] = xn[f + u]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float d = half ? o[u] : (nw[u] - o[u]);
+            const float dd = d * d;
+            s_ = s_ + dd;
+        }
+    }
+    const float root = __fsqrt_rn(s_);
+    const float nrm = shfl_f(root, (lane & 31) + 32);
+    const float rhs = a.thr * nrm;
+    const int moved = (half == 0) && (root > rhs);
+    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    float *dst = a.state_nxt + i0 * Ds + lane;
+    const float *xs = X + c_aggs + lane;                                     // row i, feature lane
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xs[(i + u) * KP];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gptr_w(dst)[(i + u) * Ds] = v[u];
     }
 }
 
@@ -161,117 +539,58 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N])
 }
 
 template <int LAYERS, int NT, int NTL, int ACT>
-__global__ void __launch_bounds__(256, 2) k_fused(const GnnFusedArgs a)
+__global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedArgs a0)
 {
+    const GnnFusedArgs &a = a0;      // (shadowed inside the tile loop)
+    // Persistent workgroup of 8 waves (one per CU): every wave pulls 32-node tiles from a device-wide counter until none
+    // is left.  Waves w and w + 4 share a SIMD; the second half starts late so that, in steady state, one partner streams
+    // neighbour rows from HBM while the other runs its MFMA / activation phases (without the offset all waves of a CU
+    // gather at once and then compute at once: HBM idles during compute, the matrix pipe during the gather).
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!gnn_gate_open(a.gate, a.world)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    if (i0 >= a.n_rows) return;                       // wave-uniform; no workgroup barrier anywhere below
-    const int nvalid = (int)((a.n_rows - i0) < 32 ? (a.n_rows - i0) : 32);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KP = a.KP, Ds = a.Ds, NLc = a.NLc;
     float *X = lds + (size_t)wave * 32 * KP;
     const int c_aggs = Ds + NLc;                      // column of the aggregated state block
+    if (wave >= GNN_FUSED_WAVES / 2)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  for (;;) {
+    int tile = 0;
+    if (lane == 0) tile = atomicAdd(a.tile_ctr, 1);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    const int64_t i0 = (int64_t)tile * 32;
+    if (i0 >= a.n_rows) break;                        // wave-uniform; no workgroup barrier anywhere in the kernel
+    const int nvalid = (int)((a0.n_rows - i0) < 32 ? (a0.n_rows - i0) : 32);
+    // Fresh, compiler-opaque copies of the pointers for every tile: without this the loop-invariant address arithmetic of
+    // the unrolled layers is hoisted out of the tile loop and spills (256 VGPRs + scratch instead of ~190).
+    GnnFusedArgs a = a0;
+    asm volatile("" : "+s"(a.Wp[0]), "+s"(a.Wp[1]), "+s"(a.Wp[2]), "+s"(a.bias[0]), "+s"(a.bias[1]), "+s"(a.bias[2]));
+    asm volatile("" : "+s"(a.bn_scale), "+s"(a.bn_shift), "+s"(a.state_cur), "+s"(a.state_nxt), "+s"(a.inv), "+s"(a.adj_src), "+s"(a.adj_w));
+    unsigned long long *stamp = a.stamps ? a.stamps + ((size_t)tile << 3) : nullptr;
+#define GNN_STAMP(slot)                                                                      \
+    do {                                                                                     \
+        if (stamp) {                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+            if (lane == 0) stamp[slot] = t_;                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+        }                                                                                    \
+    } while (0)
+    GNN_STAMP(0);
 
-    // ---- A0: zero what no phase below writes: pad columns [in_s, KP) and the rows of a partial last tile -------------
+    // the tile's 33 row pointers go through LDS: the gather re-reads them inside divergent code, where a cross-lane
+    // broadcast from lanes of another group would not be safe
+    int *ipt = reinterpret_cast<int *>(lds + (size_t)GNN_FUSED_WAVES * 32 * KP + 32) + wave * 36;
     {
-        const int padw = KP - a.in_s;
-        for (int t = lane; t < 32 * padw; t += 64) {
-            const int i = t / padw, c = t - i * padw;
-            X[i * KP + a.in_s + c] = 0.0f;
-        }
-        if (nvalid < 32)
-            for (int t = lane; t < (32 - nvalid) * a.in_s; t += 64) {
-                const int i = nvalid + t / a.in_s, c = t % a.in_s;
-                X[i * KP + c] = 0.0f;
-            }
+        const int my_ip = (lane <= nvalid) ? gload1(a.indptr + i0 + lane) : 0;
+        const int last_ip = shfl_i(my_ip, nvalid);
+        if (lane <= 32) ipt[lane] = lane <= nvalid ? my_ip : last_ip;
     }
-    // ---- A1: own state rows (contiguous in HBM) into columns [0, Ds) ------------------------------------------------
-    {
-        const float *src = a.state_cur + (a.row_begin + i0) * Ds;
-        const int total = nvalid * Ds;
-        if (a.vec == 4) {
-            int i = (lane * 4) / Ds, f = (lane * 4) - i * Ds;
-            for (int t = lane * 4; t < total; t += 256) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + t);
-                float *x = X + i * KP + f;
-                x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-                f += 256;
-                while (f >= Ds) { f -= Ds; ++i; }
-            }
-        } else {
-            int i = lane / Ds, f = lane - i * Ds;
-            for (int t = lane; t < total; t += 64) {
-                X[i * KP + f] = src[t];
-                f += 64;
-                while (f >= Ds) { f -= Ds; ++i; }
-            }
-        }
-    }
-    // ---- A2: loop-invariant label columns --------------------------------------------------------------------------
-    if (a.IW > 0) {
-        const float *src = a.inv + i0 * a.IW;
-        const int total = nvalid * a.IW;
-        for (int t = lane; t < total; t += 64) {
-            const int i = t / a.IW, c = t - i * a.IW;
-            // [nodes | agg nodes | agg arcs] -> columns Ds.., 2Ds+NLc.., 2Ds+2NLc..
-            const int col = c < NLc ? Ds + c : (c < 2 * NLc ? c_aggs + Ds + (c - NLc) : 2 * Ds + 2 * NLc + (c - 2 * NLc));
-            X[i * KP + col] = src[t];
-        }
-    }
-    // ---- A3: gather: aggregated_states = Adjacency^T . state (GNN.py:234) --------------------------------------------
-    {
-        const int lpr = a.lpr, gl = lane & (lpr - 1), grp = lane >> a.lpr_log2, groups = 64 >> a.lpr_log2;
-        const int my_ip = (lane <= nvalid) ? a.indptr[i0 + lane] : 0;      // lanes 0..32 hold the tile's row pointers
-        // one column chunk per lane (lpr * vec >= Ds is a precondition of the fused path); lanes past the row width still
-        // walk the edges (they feed the broadcasts) on column 0 and store nothing
-        const bool colok = gl * a.vec < Ds;
-        const int c0 = colok ? gl * a.vec : 0;
-        for (int pass = 0; pass * groups < 32; ++pass) {
-            const int i = pass * groups + grp;
-            const int beg = shfl_i(my_ip, i < nvalid ? i : 0), end = shfl_i(my_ip, i < nvalid ? i + 1 : 0);
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int base = beg; base < end; base += lpr) {
-                const int e = base + gl;
-                const bool has = e < end;
-                const int my_src = has ? a.adj_src[e] : 0;
-                const float my_w = has ? a.adj_w[e] : 0.0f;
-                const int cnt = (end - base) < lpr ? (end - base) : lpr;
-                for (int j = 0; j < cnt; j += 4) {
-                    float w[4];
-                    float x[4][4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int jj = (j + u < cnt) ? j + u : j;          // clamp: data of a real edge, result unused
-                        const int s = shfl_i(my_src, (grp << a.lpr_log2) + jj);
-                        w[u] = shfl_f(my_w, (grp << a.lpr_log2) + jj);
-                        const float *xp = a.state_cur + (int64_t)s * Ds + c0;
-                        if (a.vec == 4) {
-                            const float4 v = *reinterpret_cast<const float4 *>(xp);
-                            x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
-                        } else {
-                            x[u][0] = xp[0]; x[u][1] = x[u][2] = x[u][3] = 0.0f;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool on = j + u < cnt;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const float r = __builtin_fmaf(w[u], x[u][v], acc[v]);
-                            acc[v] = on ? r : acc[v];
-                        }
-                    }
-                }
-            }
-            if (i < nvalid && colok) {
-                float *x = X + i * KP + c_aggs + c0;
-                x[0] = acc[0];
-                if (a.vec == 4) { x[1] = acc[1]; x[2] = acc[2]; x[3] = acc[3]; }
-            }
-        }
-    }
+    const bool fast64 = (Ds == 64) && (nvalid == 32);     // wave-uniform: the BASELINE shape takes the unguarded paths
+    if (fast64) load_tile_fast64(a, X, ipt, i0, lane, KP, c_aggs);
+    else load_tile_generic(a, X, ipt, i0, lane, nvalid, KP, c_aggs);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    GNN_STAMP(2);
 
     // ---- B: net_state.  H^T[feature][node] = W^T . X^T on MFMA f32 32x32x2 -------------------------------------------
     const int half = lane >> 5;
@@ -279,34 +598,27 @@ __global__ void __launch_bounds__(256, 2) k_fused(const GnnFusedArgs a)
     f32x16 out[NTL];
     if constexpr (LAYERS == 1) {
         zero_acc<NTL>(out);
-        layer_from_lds<NTL>(xb, a.Wp[0] + (size_t)lane * NTL, a.kk0, out);
+        layer_from_lds<NTL>(xb, a.Wp[0] + (size_t)lane * NTL, a.kk0, out, a.wstride);
     } else {
         f32x16 h1[NT];
         zero_acc<NT>(h1);
-        layer_from_lds<NT>(xb, a.Wp[0] + (size_t)lane * NT, a.kk0, h1);
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-            tile_epilogue<ACT, false>(h1[jt], a.bias[0], nullptr, nullptr, jt, half);
-            acc_to_operand(h1[jt]);
-        }
+        layer_from_lds<NT>(xb, a.Wp[0] + (size_t)lane * NT, a.kk0, h1, a.wstride);
+        GNN_STAMP(3);
+        GNN_STAMP(4);
         if constexpr (LAYERS == 2) {
             zero_acc<NTL>(out);
-            layer_from_regs<NT, NTL>(h1, out, a.Wp[1] + (size_t)lane * NTL);
+            layer_from_regs<NT, NTL, ACT>(h1, a.bias[0], half, out, a.Wp[1] + (size_t)lane * NTL, a.wstride);
         } else {
             f32x16 h2[NT];
             zero_acc<NT>(h2);
-            layer_from_regs<NT, NT>(h1, h2, a.Wp[1] + (size_t)lane * NT);
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                tile_epilogue<ACT, false>(h2[jt], a.bias[1], nullptr, nullptr, jt, half);
-                acc_to_operand(h2[jt]);
-            }
+            layer_from_regs<NT, NT, ACT>(h1, a.bias[0], half, h2, a.Wp[1] + (size_t)lane * NT, a.wstride);
             zero_acc<NTL>(out);
-            layer_from_regs<NT, NTL>(h2, out, a.Wp[2] + (size_t)lane * NTL);
+            layer_from_regs<NT, NTL, ACT>(h2, a.bias[1], half, out, a.Wp[2] + (size_t)lane * NTL, a.wstride);
         }
     }
     // ---- C: last-layer epilogue, new state to LDS (over the aggregated-state columns, no longer needed) ---------------
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    GNN_STAMP(5);
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt) {
         if (a.bn_scale) tile_epilogue<ACT, true>(out[jt], a.bias[LAYERS - 1], a.bn_scale, a.bn_shift, jt, half);
@@ -319,33 +631,13 @@ __global__ void __launch_bounds__(256, 2) k_fused(const GnnFusedArgs a)
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // condition() for the next body: lanes 0..31 sum (new - old)^2, lanes 32..63 sum old^2, ascending feature order
-    {
-        const float *xo = X + (lane & 31) * KP, *xn = xo + c_aggs;
-        float s = 0.0f;
-        for (int f = 0; f < Ds; ++f) {
-            const float o = xo[f];
-            const float d = half ? o : (xn[f] - o);
-            const float dd = d * d;
-            s = s + dd;
-        }
-        const float root = __fsqrt_rn(s);
-        const float nrm = shfl_f(root, (lane & 31) + 32);
-        const float rhs = a.thr * nrm;
-        const int moved = (half == 0) && ((lane & 31) < nvalid) && (root > rhs);
-        if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
-    }
-    // coalesced store of the 32 new state rows (one contiguous block of HBM)
-    {
-        float *dst = a.state_nxt + i0 * Ds;
-        const int total = nvalid * Ds;
-        int i = lane / Ds, f = lane - i * Ds;
-        for (int t = lane; t < total; t += 64) {
-            dst[t] = X[i * KP + c_aggs + f];
-            f += 64;
-            while (f >= Ds) { f -= Ds; ++i; }
-        }
-    }
+    GNN_STAMP(6);
+    if (fast64) check_store_fast64(a, X, i0, lane, KP, c_aggs);
+    else check_store_generic(a, X, i0, lane, nvalid, KP, c_aggs);
+    GNN_STAMP(7);
+#undef GNN_STAMP
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next tile re-uses this wave's LDS region
+  }
 }
 
 template <int LAYERS, int NT, int NTL, int ACT>
@@ -357,7 +649,7 @@ inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipSt
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT>), grid, 256, lds_bytes, st, a);
+    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
 }
 
 // (NT, NTL) pairs that are instantiated; gnn_fused.hip rounds every net up to one of them
