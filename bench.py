@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--impl', type=int, default=1, help='1: fused kernel (default), 0: one kernel per TF op')
     ap.add_argument('--act', default='selu', help='net_state activation (experiments; the BASELINE config is selu)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-iters', type=int, default=3)
+    ap.add_argument('--cpu-iters', type=int, default=20)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))

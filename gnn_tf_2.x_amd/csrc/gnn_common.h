@@ -26,22 +26,18 @@ int gnn_fail(int code, const char *fmt, ...);
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float gnn_expf(float x)
 {
-    // branch-free form of oracle/gnn_oracle.c:orc_expf: same operations on the in-range path, selects for the rest.
-    // ldexpf(y, n) == (y * 2^(n/2)) * 2^(n - n/2) bit for bit (both scale exactly and round once, on underflow only).
+    // branch-free form of oracle/gnn_oracle.c:orc_expf: same operations on the in-range path, selects for the rest
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -87.33654022216797f), 88.72283935546875f);
-    const float n = __builtin_rintf(xc * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693359375f, xc);
-    r = __builtin_fmaf(n, 2.12194440e-4f, r);
-    const float z = r * r;
-    float p = 1.9875691500e-4f;
-    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-    float y = __builtin_fmaf(p, z, r);
-    y = y + 1.0f;
-    float e = __builtin_ldexpf(y, (int)n);
+    const float u = xc * 1.44269504088896341f;
+    const float n = __builtin_rintf(u);
+    const float f = u - n;
+    float p = 0.0013218672247603536f;
+    p = __builtin_fmaf(p, f, 0.009671698324382305f);
+    p = __builtin_fmaf(p, f, 0.05550893023610115f);
+    p = __builtin_fmaf(p, f, 0.24022237956523895f);
+    p = __builtin_fmaf(p, f, 0.6931468844413757f);
+    p = __builtin_fmaf(p, f, 1.0f);
+    float e = __builtin_ldexpf(p, (int)n);
     e = x > 88.72283935546875f ? __builtin_inff() : e;
     e = x < -87.33654022216797f ? 0.0f : e;
     return x != x ? x : e;

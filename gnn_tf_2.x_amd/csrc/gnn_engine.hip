@@ -203,23 +203,41 @@ __global__ void k_softmax_bn(int64_t n, int n_out, float *Y, int64_t ldy, const 
     }
 }
 
-// condition(): per owned node sqrt(sum (s-so)^2) > thr * sqrt(sum so^2); OR into *flag_out.  so == nullptr: ones.
-__global__ void k_check(int64_t n_rows, int d, const float *__restrict__ s, const float *__restrict__ so, float thr,
-                        int *flag_out, const int *gate, int world)
+// condition(): per owned node sqrt(sum (s-so)^2) > thr * sqrt(sum so^2); OR into the rank's flag.  so == nullptr: ones.
+// One thread per row keeps the oracle's ascending-feature summation order; the rows of a block are staged through LDS in
+// chunks of 32 features so that HBM is read in full 128-byte segments.
+__global__ void __launch_bounds__(256) k_check(int64_t n_rows, int d, const float *__restrict__ s,
+                                               const float *__restrict__ so, float thr, int *flag_out, const int *gate,
+                                               int world)
 {
+    __shared__ float ts[256 * 33], to[256 * 33];
     if (!gnn_gate_open(gate, world)) return;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t i = r0 + threadIdx.x;
+    float dist = 0.0f, nrm = 0.0f;
+    for (int c0 = 0; c0 < d; c0 += 32) {
+        const int cw = (d - c0) < 32 ? (d - c0) : 32;
+        __syncthreads();
+        for (int t = threadIdx.x; t < 256 * 32; t += 256) {
+            const int r = t >> 5, c = t & 31;
+            if (c < cw && r0 + r < n_rows) {
+                ts[r * 33 + c] = s[(r0 + r) * d + c0 + c];
+                if (so) to[r * 33 + c] = so[(r0 + r) * d + c0 + c];
+            }
+        }
+        __syncthreads();
+        if (i < n_rows)
+            for (int c = 0; c < cw; ++c) {
+                const float o = so ? to[threadIdx.x * 33 + c] : 1.0f;
+                const float df = ts[threadIdx.x * 33 + c] - o;
+                const float dd = df * df;
+                dist = dist + dd;
+                const float oo = o * o;
+                nrm = nrm + oo;
+            }
+    }
     int f = 0;
     if (i < n_rows) {
-        float dist = 0.0f, nrm = 0.0f;
-        for (int c = 0; c < d; ++c) {
-            const float o = so ? so[i * d + c] : 1.0f;
-            const float df = s[i * d + c] - o;
-            const float dd = df * df;
-            dist = dist + dd;
-            const float oo = o * o;
-            nrm = nrm + oo;
-        }
         const float lhs = __fsqrt_rn(dist);
         const float rn = __fsqrt_rn(nrm);
         const float rhs = thr * rn;
@@ -228,13 +246,18 @@ __global__ void k_check(int64_t n_rows, int d, const float *__restrict__ s, cons
     if (__any(f) && (threadIdx.x & 63) == 0) gnn_flag_raise(flag_out);
 }
 
-// k_final = number of executed bodies = first k whose gate is closed (or max_iter)
+// k_final = number of executed bodies = first k whose gate is closed (or max_iter); one wave, 64 gates per pass
 __global__ void k_finalize(const int *flags, int world, int max_iter, int *kfinal)
 {
-    if (threadIdx.x | blockIdx.x) return;
-    int k = 0;
-    while (k < max_iter && gnn_gate_open(flags + (size_t)k * world * GNN_FLAG_WORDS, world)) ++k;
-    *kfinal = k;
+    const int lane = threadIdx.x;
+    int k_final = max_iter;
+    for (int k0 = 0; k0 < max_iter; k0 += 64) {
+        const int k = k0 + lane;
+        const bool closed = k < max_iter && !gnn_gate_open(flags + (size_t)k * world * GNN_FLAG_WORDS, world);
+        const unsigned long long m = __ballot(closed);
+        if (m) { k_final = k0 + __builtin_ctzll(m); break; }
+    }
+    if (lane == 0) *kfinal = k_final;
 }
 
 // apply_filters(): feats[m] = [state_final[row_m] | nodes[row_m] (iff D > 0)]

@@ -86,22 +86,18 @@ __device__ __forceinline__ float act_t(float v)
 {
     if constexpr (ACT == GNN_ACT_SELU) {
         // gnn_act(v, SELU) with the parts of gnn_expf that cannot influence the result removed: exp is only used for
-        // v <= 0 (no overflow side), NaN propagates through the arithmetic, and the underflow select stays.  On every
-        // input this returns the same bits as the generic form.
-        const float n = __builtin_rintf(v * 1.44269504088896341f);
-        float r = __builtin_fmaf(n, -0.693359375f, v);
-        r = __builtin_fmaf(n, 2.12194440e-4f, r);
-        const float z = r * r;
-        float p = 1.9875691500e-4f;
-        p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-        p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-        p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-        p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-        p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-        float y = __builtin_fmaf(p, z, r);
-        y = y + 1.0f;
-        float e = __builtin_ldexpf(y, (int)n);
-        e = v < -87.33654022216797f ? 0.0f : e;
+        // v <= 0 (no overflow side), NaN propagates through the arithmetic, and below the underflow threshold both forms
+        // give e - 1 == -1.  On every input this returns the same bits as the generic form.
+        const float u = v * 1.44269504088896341f;
+        const float n = __builtin_rintf(u);
+        const float f = u - n;
+        float p = 0.0013218672247603536f;
+        p = __builtin_fmaf(p, f, 0.009671698324382305f);
+        p = __builtin_fmaf(p, f, 0.05550893023610115f);
+        p = __builtin_fmaf(p, f, 0.24022237956523895f);
+        p = __builtin_fmaf(p, f, 0.6931468844413757f);
+        p = __builtin_fmaf(p, f, 1.0f);
+        const float e = __builtin_ldexpf(p, (int)n);
         const float neg = 1.6732632423543772f * (e - 1.0f);
         return 1.0507009873554805f * (v > 0.0f ? v : neg);
     } else {
@@ -174,41 +170,38 @@ __device__ __forceinline__ void layer_from_lds(const float *xb, const float *wp,
 // BETWEEN the MFMAs to overlap with them).  The concatenation of the stages is exactly act_t<ACT>(v + bias).
 template <int ACT>
 struct ActPipe {
-    float t, n, r, z, p, e;
+    float t, n, f, p, e;
     __device__ __forceinline__ void s0(float v, float bias)
     {
         t = v + bias;
         if constexpr (ACT == GNN_ACT_SELU) {
-            n = __builtin_rintf(t * 1.44269504088896341f);
-            r = __builtin_fmaf(n, -0.693359375f, t);
-            r = __builtin_fmaf(n, 2.12194440e-4f, r);
-            z = r * r;
+            const float u = t * 1.44269504088896341f;
+            n = __builtin_rintf(u);
+            f = u - n;
         }
     }
     __device__ __forceinline__ void s1()
     {
         if constexpr (ACT == GNN_ACT_SELU) {
-            p = 1.9875691500e-4f;
-            p = __builtin_fmaf(p, r, 1.3981999507e-3f);
-            p = __builtin_fmaf(p, r, 8.3334519073e-3f);
-            p = __builtin_fmaf(p, r, 4.1665795894e-2f);
-            p = __builtin_fmaf(p, r, 1.6666665459e-1f);
-            p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+            p = 0.0013218672247603536f;
+            p = __builtin_fmaf(p, f, 0.009671698324382305f);
+            p = __builtin_fmaf(p, f, 0.05550893023610115f);
+            p = __builtin_fmaf(p, f, 0.24022237956523895f);
+            p = __builtin_fmaf(p, f, 0.6931468844413757f);
+            p = __builtin_fmaf(p, f, 1.0f);
         }
     }
     __device__ __forceinline__ void s2()
     {
         if constexpr (ACT == GNN_ACT_SELU) {
-            float y = __builtin_fmaf(p, z, r);
-            y = y + 1.0f;
-            e = __builtin_ldexpf(y, (int)n);
+            e = __builtin_ldexpf(p, (int)n);
+            e = e - 1.0f;
         }
     }
     __device__ __forceinline__ float s3()
     {
         if constexpr (ACT == GNN_ACT_SELU) {
-            e = t < -87.33654022216797f ? 0.0f : e;
-            const float neg = 1.6732632423543772f * (e - 1.0f);
+            const float neg = 1.6732632423543772f * e;
             return 1.0507009873554805f * (t > 0.0f ? t : neg);
         } else {
             return gnn_act(t, ACT);
@@ -554,12 +547,14 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     const int c_aggs = Ds + NLc;                      // column of the aggregated state block
     if (wave >= GNN_FUSED_WAVES / 2)
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  for (;;) {
     int tile = 0;
     if (lane == 0) tile = atomicAdd(a.tile_ctr, 1);
     tile = __builtin_amdgcn_readfirstlane(tile);
+  for (;;) {
     const int64_t i0 = (int64_t)tile * 32;
     if (i0 >= a.n_rows) break;                        // wave-uniform; no workgroup barrier anywhere in the kernel
+    int next_tile = 0;                                // the next ticket is drawn now; its latency hides behind this tile
+    if (lane == 0) next_tile = atomicAdd(a0.tile_ctr, 1);
     const int nvalid = (int)((a0.n_rows - i0) < 32 ? (a0.n_rows - i0) : 32);
     // Fresh, compiler-opaque copies of the pointers for every tile: without this the loop-invariant address arithmetic of
     // the unrolled layers is hoisted out of the tile loop and spills (256 VGPRs + scratch instead of ~190).
@@ -637,6 +632,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     GNN_STAMP(7);
 #undef GNN_STAMP
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next tile re-uses this wave's LDS region
+    tile = __builtin_amdgcn_readfirstlane(next_tile);
   }
 }
 
