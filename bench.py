@@ -125,10 +125,11 @@ def main():
     if world > 1:
         uid, id_path = rendezvous_id(rank, world, engine)
         comm = engine.Comm(uid, rank, world, local_rank)
-    rb, nr = engine.shard_range(n, rank, world)
-    e0, e1 = int(s['indptr'][rb]), int(s['indptr'][rb + nr])
-    graph = engine.Graph(n, s['indptr'][rb:rb + nr + 1] - e0, s['adj_src'][e0:e1], s['adj_w'][e0:e1], s['arc_w'][e0:e1],
-                         s['arc_labels_csr'][e0:e1], s['nodes'], np.ones(nr, np.uint8), row_begin=rb, device=local_rank)
+    rb, nr, indptr, adj_src, adj_w, arc_w, arc_lab = engine.shard_csr(n, rank, world, s['indptr'], s['adj_src'], s['adj_w'],
+                                                                        s['arc_w'], s['arc_labels_csr'])
+    n_arcs_local = len(adj_src)
+    graph = engine.Graph(n, indptr, adj_src, adj_w, arc_w, arc_lab, s['nodes'], np.ones(nr, np.uint8), row_begin=rb,
+                         device=local_rank)
     loop = engine.Loop(graph, engine.Mlp(st['weights'], st['activations'], True, device=local_rank),
                        engine.Mlp(ou['weights'], ou['activations'], True, device=local_rank), d, args.max_iter, 0.0, comm)
     impl_used = loop.set_impl(args.impl)
@@ -150,11 +151,26 @@ def main():
     elapsed = barrier(time.perf_counter() - t0)          # device sync, then max over ranks
     loop.set_profiling(False)
 
+    # boundary-inclusive rate (never `value`): host state0 in, host state + output back, one Loop (DESIGN.md "Measurement")
+    t1 = time.perf_counter()
+    loop.set_state0(state0[rb:rb + nr])
+    k_e2e = loop.run()
+    loop.state(), loop.output()
+    e2e_s = time.perf_counter() - t1
+
     if rank == 0:
         updates = n * k_total
         kernel_ms = float(np.mean(iter_ms))
-        alg_bytes = algorithmic_bytes_per_iteration(nr, e1 - e0, d, nl, al)
+        alg_bytes = algorithmic_bytes_per_iteration(nr, n_arcs_local, d, nl, al)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run of this same command
+        # (tools/profile.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if world == 1 and impl_used and args.nodes == 1_000_000 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
+            traffic_src = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)'
         line = {
             'metric': 'node-state-updates/sec (nodes x iters / s), 1M-node synthetic graph',
             'value': updates / elapsed, 'unit': 'node-state-updates/s', 'n_gpus': world, 'steps': args.steps,
@@ -165,9 +181,10 @@ def main():
                                    f'max_iter={args.max_iter}, threshold=0 (all iterations run)',
                        'iterations_per_step': k_total / args.steps,
                        'parallelism': f'node-range shards x{world}, RCCL all-gather of state rows per iteration' if world > 1 else 'single GPU',
-                       'impl': 'fused gather+MLP kernel' if impl_used else 'one kernel per TF op (unfused)'},
+                       'impl': 'fused gather+MLP kernel' if impl_used else 'one kernel per TF op (unfused)',
+                       'pcie_inclusive_updates_per_s': nr * k_e2e / e2e_s},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None,
+                         'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'gnn_fused_iteration' if impl_used else 'spmm + dense x3 + check (sum of the per-iteration kernels)',
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': kernel_ms},
         }

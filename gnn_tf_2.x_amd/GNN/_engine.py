@@ -87,6 +87,15 @@ def shard_range(n_nodes: int, rank: int, world: int) -> tuple[int, int]:
     return b.value, n.value
 
 
+def shard_csr(n_nodes: int, rank: int, world: int, indptr, *per_entry_arrays):
+    """Node-range shard of a CSR-by-destination graph: (row_begin, n_rows, local indptr, sliced per-entry arrays...).
+    Source ids inside the slices stay GLOBAL (every rank keeps a full replica of the state)."""
+    rb, nr = shard_range(n_nodes, rank, world)
+    indptr = np.asarray(indptr)
+    e0, e1 = int(indptr[rb]), int(indptr[rb + nr])
+    return (rb, nr, (indptr[rb:rb + nr + 1] - e0).astype(np.int32)) + tuple(np.asarray(a)[e0:e1] for a in per_entry_arrays)
+
+
 class Graph:
     """Device-resident graph (gnn_graph).  CSR "by destination" as produced by graph_class.GraphTensor."""
 

@@ -1,0 +1,91 @@
+"""Worker of tests/test_sharded_gloo.py (one process per rank, gloo on CPU).
+
+Runs the node-range sharded loop with the SAME plan and exchange protocol as the engine's multi-GPU path
+(gnn_shard_range / _engine.shard_csr; per iteration: owned rows computed locally, all-gather of the owned state rows padded
+to the shard size + all-gather of the per-rank convergence flag, every rank ORs the flags) but with the oracle's row-wise
+arithmetic in place of the HIP kernels, and compares with the single-process oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'gnn_tf_2.x_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+
+from GNN import _engine, GNN_utils as utils      # noqa: E402  (loads libgnn_hip.so; no GPU call is made)
+from oracle import c_oracle as corc              # noqa: E402
+from oracle import gnn_oracle as orc             # noqa: E402
+from util import make_mlp                        # noqa: E402
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n, d, nl, al, max_it, thr = 1000, 8, 3, 1, 25, 0.01
+    s = utils.syntheticGraph(n, 8.0, nl, al, 2, seed=77)
+    rng = np.random.default_rng(5)
+    st = make_mlp(rng, al + 2 * (nl + d), [16, d], 'selu', gain=0.6)
+    ou = make_mlp(rng, nl + d, [2], 'softmax')
+    state0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+
+    rb, nr, indptr, adj_src, adj_w, arc_w, arc_lab = _engine.shard_csr(n, rank, world, s['indptr'], s['adj_src'], s['adj_w'],
+                                                                        s['arc_w'], s['arc_labels_csr'])
+    shard = ((n + world - 1) // world + 31) // 32 * 32
+    assert rb == min(n, shard * rank) and nr == min(n, shard * (rank + 1)) - rb
+    ranges = [_engine.shard_range(n, r, world) for r in range(world)]
+    assert sum(c for _, c in ranges) == n and all(ranges[i][0] + ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+
+    local = (indptr, adj_src, adj_w)
+    agg_nodes = corc.spmm(local, s['nodes'])                                         # GNN.py:263 on the owned rows
+    agg_arcs = corc.spmm((indptr, np.arange(len(arc_w), dtype=np.int32), arc_w), arc_lab)   # GNN.py:259
+
+    def any_flag(flag):
+        out = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([int(flag)], dtype=torch.int32))
+        return any(int(t.item()) for t in out)
+
+    # padded replica -> global rows: shard p holds rows [p*shard, p*shard + count_p)
+    def to_global(full_padded):
+        return np.concatenate([full_padded[p * shard:p * shard + ranges[p][1]] for p in range(world)])
+
+    def gather_state(own):
+        buf = np.zeros((shard, own.shape[1]), np.float32)
+        buf[:nr] = own
+        out = [torch.zeros(shard, own.shape[1]) for _ in range(world)]
+        dist.all_gather(out, torch.from_numpy(buf))
+        return to_global(np.concatenate([t.numpy() for t in out]))
+
+    state = gather_state(state0[rb:rb + nr])
+    assert np.array_equal(state, state0)
+    go = any_flag(orc.not_converged(state[rb:rb + nr], np.ones((nr, d), np.float32), thr).any())
+    k = 0
+    while go and k < max_it:
+        own = state[rb:rb + nr]
+        inp = np.concatenate([own, s['nodes'][rb:rb + nr], corc.spmm(local, state), agg_nodes, agg_arcs], axis=1)
+        new = corc.mlp_forward(inp, st['weights'], st['activations'], True)
+        flag = orc.not_converged(new, own, thr).any()
+        state = gather_state(new)
+        go = any_flag(flag)
+        k += 1
+
+    # single-process oracle on the whole graph
+    arcs = np.concatenate([np.stack([s['src'], s['dst']], 1).astype(np.float32), s['arc_labels']], axis=1)
+    g = dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
+             adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
+    kc, sc, _ = corc.loop_node(g, st, ou, d, max_it, thr, state0)
+    ks = [torch.zeros(1, dtype=torch.int32) for _ in range(world)]
+    dist.all_gather(ks, torch.tensor([k], dtype=torch.int32))
+    assert len({int(t.item()) for t in ks}) == 1, 'ranks disagree on the iteration count'
+    assert k == kc and 1 < k < max_it, (k, kc)
+    assert np.array_equal(state, sc), 'sharded state differs from the single-process oracle'
+    dist.barrier()
+    if rank == 0:
+        print(f'SHARDED_OK world={world} k={k}')
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

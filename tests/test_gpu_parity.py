@@ -196,6 +196,40 @@ def test_graph_based_readout_and_errors():
         _models(st, make_mlp(rng, nl + 1, [2], 'softmax'), 0, 5, 0.01, GNNnodeBased).Loop(go)   # wrong net_output width
 
 
+def test_mutag_batches_graph_based():
+    """BASELINE config 2: MUTAG batches of 32 graphs, graph-based, state = node labels (14), net_state 31 -> [32, 32, 14],
+    max_iteration 50: k, states and graph outputs against the C oracle; LGNN on the same batch."""
+    import load_MUTAG
+    from GNN.GNN import GNNgraphBased
+    from GNN.LGNN import LGNN
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(31)
+    graphs = load_MUTAG.load(limit=96)
+    st, ou = make_mlp(rng, 3 + 2 * 14, [32, 32, 14], 'selu', gain=0.7), make_mlp(rng, 14, [2], 'softmax')
+    gnn = _models(st, ou, 0, 50, 0.01, GNNgraphBased)
+    for b in range(3):
+        batch = GraphObject.merge(graphs[32 * b:32 * b + 32], problem_based='g', aggregation_mode='average')
+        k, s, o = gnn.Loop(batch)
+        gd = orc.make_graph_dict(batch.arcs, batch.nodes, 'average', NodeGraph=batch.NodeGraph)
+        kc, sc, on = corc.loop_node(gd, st, ou, 0, 50, 0.01)
+        assert k == kc and np.array_equal(s, sc)
+        assert o.shape == (32, 2) and np.array_equal(o, corc.readout(batch.NodeGraph, on))
+        it, loss, targs, out = gnn.evaluate_single_graph(batch, training=False)
+        assert targs.shape == (32, 2) and np.array_equal(out, o)
+    gnn.impl = 0
+    assert np.array_equal(gnn.Loop(batch)[2], o)          # per-op kernels give the same bits
+    # graph-based LGNN, 2 layers, outputs propagated
+    ins, ls = orc.get_inout_dims('state', 14, 3, 2, 'g', 0, [32], layer=1, get_output=True)
+    ino, lo = orc.get_inout_dims('output', 14, 3, 2, 'g', 0, None, layer=1, get_output=True)
+    st1, ou1 = make_mlp(rng, ins, ls, 'selu', gain=0.7), make_mlp(rng, ino, lo, 'softmax')
+    lgnn = LGNN([_models(st, ou, 0, 50, 0.01, GNNgraphBased), _models(st1, ou1, 0, 50, 0.01, GNNgraphBased)], False, True, None, None, None, 'c')
+    K, state, outs = lgnn.Loop(batch)
+    gnns = [dict(net_state=st, net_output=ou, state_vect_dim=0, max_iteration=50, threshold=0.01),
+            dict(net_state=st1, net_output=ou1, state_vect_dim=0, max_iteration=50, threshold=0.01)]
+    K64, s64, o64 = orc.lgnn_loop(gd, gnns, False, True, True, None, np.float64)
+    assert K == K64 and len(outs) == 2 and np.max(np.abs(outs[1] - o64[1])) < 1e-5 and np.max(np.abs(outs[0] - o64[0])) < 1e-5
+
+
 def test_lgnn_stack_on_device():
     from GNN.GNN import GNNnodeBased
     from GNN.LGNN import LGNN

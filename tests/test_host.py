@@ -157,3 +157,29 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.gnn_version.restype = ctypes.c_int
     assert lib.gnn_version() == 1
+
+
+def test_mutag_loader_follows_reference_semantics():
+    """The loader against a literal (slow, mask-based) restatement of reference load_MUTAG.py:14-52 on the first graphs,
+    and the dataset totals of SURVEY.md section 6."""
+    import load_MUTAG
+    graphs = load_MUTAG.load()
+    assert len(graphs) == 4337 and sum(g.nodes.shape[0] for g in graphs) == 131488 and sum(g.arcs.shape[0] for g in graphs) == 266894
+    assert graphs[0].DIM_NODE_LABEL == 14 and graphs[0].DIM_ARC_LABEL == 3 and graphs[0].DIM_TARGET == 2
+    assert int(sum(g.targets[0, 0] for g in graphs)) == 2401
+    edgesIDs, edgesL, nodesL, gIDs_nodes, gtargs = load_MUTAG._raw()
+    _, idx = np.unique(gIDs_nodes, return_index=True)
+    idx = np.concatenate([idx, [len(gIDs_nodes)]]).tolist()
+    edgesIDs = np.unique(edgesIDs, axis=0)
+    eL = np.zeros((edgesL.shape[0], len(np.unique(edgesL))), dtype=int)
+    eL[range(eL.shape[0]), edgesL] = 1
+    for g in range(40):
+        i, j = idx[g], idx[g + 1]
+        k = (edgesIDs > i) * (edgesIDs <= j)
+        mask = (k[:, 0] * k[:, 1]).astype(bool)
+        ids = edgesIDs[mask, :].copy()
+        for new, old in enumerate(np.unique(ids)):
+            ids[ids == old] = new
+        arcs = np.concatenate([ids, eL[mask]], axis=1)
+        assert np.array_equal(graphs[g].arcs, arcs.astype(np.float32))
+        assert graphs[g].nodes.shape == (j - i, 14) and graphs[g].NodeGraph.shape == (j - i, 1)
