@@ -16,6 +16,7 @@ struct GnnFusedArgs {
     // state
     const float *state_cur;  // [N_pad, Ds] all nodes
     float *state_nxt;        // owned rows
+    int64_t state_bytes;     // size of the replica state_cur points to
     // shapes
     int Ds, NLc, AL, IW, in_s, KP, lpr, lpr_log2, vec, kk0;
     // layers: packed weights [kk][lane][tiles of the layer], biases padded to whole tiles

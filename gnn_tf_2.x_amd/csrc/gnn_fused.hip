@@ -119,6 +119,7 @@ bool gnn_fused_supported(const gnn_loop *l)
     if (lds_bytes(p) > 160 * 1024) return false;                            // one 8-wave workgroup per CU
     const int Ds = l->Ds;
     if (!((Ds % 4 == 0 && Ds <= 256) || Ds <= 64)) return false;           // one column chunk per lane in the gather
+    if ((int64_t)l->N_pad * Ds * (int64_t)sizeof(float) >= ((int64_t)1 << 31)) return false;   // 32-bit row offsets
     return l->g->n_rows > 0;
 }
 
@@ -157,6 +158,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.indptr = g->sh->indptr; a.adj_src = g->sh->adj_src; a.adj_w = g->sh->adj_w;
     a.inv = l->inv;
     a.state_cur = l->state[cur];
+    a.state_bytes = (int64_t)l->N_pad * l->Ds * (int64_t)sizeof(float);
     a.state_nxt = l->state[nxt] + (size_t)g->row_begin * l->Ds;
     a.Ds = l->Ds; a.NLc = l->NLc; a.AL = g->AL; a.IW = 2 * l->NLc + g->AL; a.in_s = l->in_s; a.KP = p.KP; a.kk0 = p.kk0;
     a.vec = (l->Ds % 4 == 0) ? 4 : 1;

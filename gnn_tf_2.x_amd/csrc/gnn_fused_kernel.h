@@ -23,6 +23,8 @@
 // Template parameters: LAYERS Dense layers; NT 32-wide feature tiles of every hidden layer; NTL tiles of the last layer;
 // ACT the activation shared by all layers (gnn_activation).
 #pragma once
+#include <utility>
+
 #include "gnn_common.h"
 #include "gnn_fused.h"
 
@@ -50,6 +52,15 @@ __device__ __forceinline__ float shfl_f(float v, int src_lane)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 __device__ __forceinline__ int shfl_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+// lane J of every 16-lane row broadcast to the whole row: one VALU move (DPP row_newbcast), no LDS crossbar, no wait
+template <int J>
+__device__ __forceinline__ int row_bcast_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);
+}
+template <int J>
+__device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast_i<J>(__float_as_int(v))); }
 
 // after this, for q = 0..3: registers {4q, 4q+2, 4q+1, 4q+3} hold, in that order, the k pairs (8q, 8q+1), (8q+2, 8q+3),
 // (8q+4, 8q+5), (8q+6, 8q+7) of the tile: lower half-wave the even k, upper half-wave the odd k (MFMA B-operand order)
@@ -165,46 +176,35 @@ __device__ __forceinline__ void layer_from_lds(const float *xb, const float *wp,
 #undef GNN_L0_MFMA
 }
 
-// Activation split into four stages so that it can be issued in the shadow of consecutive MFMAs (an MFMA occupies the
-// matrix pipe for 64 cycles but the wave's issue port only briefly; the wave issues in order, so VALU work has to sit
-// BETWEEN the MFMAs to overlap with them).  The concatenation of the stages is exactly act_t<ACT>(v + bias).
+// Activation of a PAIR of accumulator elements, split into eight stages so that it can be issued in the shadow of
+// consecutive MFMAs (the wave issues in order, so VALU work has to sit BETWEEN the MFMAs to overlap with anything).  The
+// arithmetic runs on packed float2 operands (v_pk_mul/add/fma_f32: two IEEE results per issue slot, the same bits as the
+// scalar instructions).  The concatenation of the stages is exactly act_t<ACT>(v + bias) on both elements.
 template <int ACT>
-struct ActPipe {
-    float t, n, f, p, e;
-    __device__ __forceinline__ void s0(float v, float bias)
-    {
-        t = v + bias;
-        if constexpr (ACT == GNN_ACT_SELU) {
-            const float u = t * 1.44269504088896341f;
-            n = __builtin_rintf(u);
-            f = u - n;
-        }
-    }
-    __device__ __forceinline__ void s1()
+struct ActPipe2 {
+    v2f t, u, n, f, p, e;
+    static __device__ __forceinline__ v2f splat(float c) { return v2f{c, c}; }
+    __device__ __forceinline__ void stage(int st, float v0, float v1, float b0, float b1, float &o0, float &o1)
     {
         if constexpr (ACT == GNN_ACT_SELU) {
-            p = 0.0013218672247603536f;
-            p = __builtin_fmaf(p, f, 0.009671698324382305f);
-            p = __builtin_fmaf(p, f, 0.05550893023610115f);
-            p = __builtin_fmaf(p, f, 0.24022237956523895f);
-            p = __builtin_fmaf(p, f, 0.6931468844413757f);
-            p = __builtin_fmaf(p, f, 1.0f);
-        }
-    }
-    __device__ __forceinline__ void s2()
-    {
-        if constexpr (ACT == GNN_ACT_SELU) {
-            e = __builtin_ldexpf(p, (int)n);
-            e = e - 1.0f;
-        }
-    }
-    __device__ __forceinline__ float s3()
-    {
-        if constexpr (ACT == GNN_ACT_SELU) {
-            const float neg = 1.6732632423543772f * e;
-            return 1.0507009873554805f * (t > 0.0f ? t : neg);
+            switch (st) {
+            case 0: t = v2f{v0, v1} + v2f{b0, b1}; u = t * splat(1.44269504088896341f); break;
+            case 1: n = v2f{__builtin_rintf(u.x), __builtin_rintf(u.y)}; f = u - n; break;
+            case 2: p = __builtin_elementwise_fma(splat(0.0013218672247603536f), f, splat(0.009671698324382305f));
+                    p = __builtin_elementwise_fma(p, f, splat(0.05550893023610115f)); break;
+            case 3: p = __builtin_elementwise_fma(p, f, splat(0.24022237956523895f));
+                    p = __builtin_elementwise_fma(p, f, splat(0.6931468844413757f)); break;
+            case 4: p = __builtin_elementwise_fma(p, f, splat(1.0f)); break;
+            case 5: e = v2f{__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)}; e = e - splat(1.0f); break;
+            case 6: e = e * splat(1.6732632423543772f); break;
+            case 7: {
+                const v2f r = v2f{t.x > 0.0f ? t.x : e.x, t.y > 0.0f ? t.y : e.y} * splat(1.0507009873554805f);
+                o0 = r.x; o1 = r.y;
+            } break;
+            }
         } else {
-            return gnn_act(t, ACT);
+            if (st == 0) t = v2f{v0, v1} + v2f{b0, b1};
+            if (st == 7) { o0 = gnn_act(t.x, ACT); o1 = gnn_act(t.y, ACT); }
         }
     }
 };
@@ -238,32 +238,29 @@ __device__ __forceinline__ void layer_from_regs(f32x16 (&hin)[NI], const float *
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        ActPipe2<ACT> ap;
 #pragma unroll
         for (int ss = 0; ss < 16; ++ss) {
             const int s = 16 * ti + ss;
             if (s + DEPTH < STEPS) load_w<NO>(wp + (size_t)(s + DEPTH) * 64 * NO * wstride, w[s + DEPTH]);
             const int reg = 4 * (ss >> 2) + ((ss & 3) == 1 ? 2 : (ss & 3) == 2 ? 1 : (ss & 3));
             const float b = hin[ti][reg];
-            ActPipe<ACT> ap;
             const bool epi = ti + 1 < NI;
+            const int pe = ss & ~1;                                  // the pair (pe, pe + 1) spans steps pe and pe + 1
 #pragma unroll
             for (int jt = 0; jt < NO; ++jt) {
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][jt], b, acc[jt], 0, 0, 0);
-                if (epi) {      // stage(s) of the epilogue of element ss of tile ti + 1, in the shadow of this MFMA
+                if (epi) {      // stages of the epilogue of elements (pe, pe + 1) of tile ti + 1, in the shadow of this MFMA
                     constexpr int SPM = 4 / NO;                      // stages per MFMA: NO = 4 -> 1, 2 -> 2, 1 -> 4
 #pragma unroll
-                    for (int st = jt * SPM; st < (jt + 1) * SPM; ++st) {
-                        if (st == 0) ap.s0(hin[ti + 1][ss], nb[ss]);
-                        if (st == 1) ap.s1();
-                        if (st == 2) ap.s2();
-                        if (st == 3) {
-                            hin[ti + 1][ss] = ap.s3();
-                            if (ss & 1) {
-                                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(hin[ti + 1][ss - 1]),
-                                                                           __float_as_uint(hin[ti + 1][ss]), false, false);
-                                hin[ti + 1][ss - 1] = __uint_as_float(sw[0]);
-                                hin[ti + 1][ss] = __uint_as_float(sw[1]);
-                            }
+                    for (int q = jt * SPM; q < (jt + 1) * SPM; ++q) {
+                        const int st = (ss & 1) * 4 + q;             // even step: stages 0..3, odd step: stages 4..7
+                        float o0 = 0.0f, o1 = 0.0f;
+                        ap.stage(st, hin[ti + 1][pe], hin[ti + 1][pe + 1], nb[pe], nb[pe + 1], o0, o1);
+                        if (st == 7) {
+                            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o0), __float_as_uint(o1), false, false);
+                            hin[ti + 1][pe] = __uint_as_float(sw[0]);
+                            hin[ti + 1][pe + 1] = __uint_as_float(sw[1]);
                         }
                     }
                 }
@@ -348,6 +345,16 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
     }
 }
 
+// one batch of the Ds == 64 gather: entry J of the group's batch (held by lane J of the 16-lane row) is broadcast to the
+// row, and the 16 lanes request the 256-byte neighbour row, 16 B each
+template <int GB, int... J>
+__device__ __forceinline__ void gather_batch(int my_src, float my_w, __amdgpu_buffer_rsrc_t rsrc, int voff0, float (&w)[GB],
+                                             v4f (&x)[GB], std::integer_sequence<int, J...>)
+{
+    ((w[J] = row_bcast_f<J>(my_w),
+      x[J] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row_bcast_i<J>(my_src) << 8) + voff0, 0, 0))), ...);
+}
+
 // Ds == 64, full tile.  Lane group g (16 lanes, 16 B per lane = one 256 B state row per group and instruction) owns the
 // 8 consecutive nodes 8g..8g+7 and walks their contiguous CSR entries in batches of GB: ids/weights of a batch are fetched
 // coalesced by the group (and those of the next batch prefetched), the GB neighbour rows are all requested before the
@@ -380,7 +387,10 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
     const int e_begin = ipt[node], e_end = ipt[node_end];
     int next_end = ipt[node + 1];
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    const float *sc = a.state_cur + gl * 4;
+    // neighbour rows through a buffer descriptor: 32-bit byte offsets (src * 256 + 16 * lane-in-row) instead of 64-bit
+    // pointer arithmetic per row; the state replica is < 4 GiB by the fused path's precondition
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.state_cur), 0, (int)a.state_bytes, 0x00020000);
+    const int voff0 = gl * 16;
     float *xo = X + c_aggs + gl * 4;
 #define GNN_ROW_BOUNDARY(e)                                                                     \
     while ((e) >= next_end) {                                                                   \
@@ -397,12 +407,7 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
     for (; base + GB <= e_end; base += GB) {                                 // full batches: no guards
         float w[GB];
         v4f x[GB];
-#pragma unroll
-        for (int u = 0; u < GB; ++u) {
-            const int s_ = shfl_i(my_src, gbase + u);
-            w[u] = shfl_f(my_w, gbase + u);
-            x[u] = gload4(sc + (int64_t)s_ * Ds);
-        }
+        gather_batch<GB>(my_src, my_w, rsrc, voff0, w, x, std::make_integer_sequence<int, GB>{});
         const int nb = base + GB + gl;                                       // ids / weights of the next batch
         my_src = 0; my_w = 0.0f;
         if (nb < e_end) { my_src = gload1(a.adj_src + nb); my_w = gload1(a.adj_w + nb); }
@@ -417,13 +422,9 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
         const int cnt = e_end - base;
         float w[GB];
         v4f x[GB];
-#pragma unroll
-        for (int u = 0; u < GB; ++u) {
-            const int uu = u < cnt ? u : 0;                                  // clamp: re-reads entry 0, result unused
-            const int s_ = shfl_i(my_src, gbase + uu);                       // (cnt == 0: lane value 0 = row 0, unused)
-            w[u] = shfl_f(my_w, gbase + uu);
-            x[u] = gload4(sc + (int64_t)s_ * Ds);
-        }
+        // all GB slots are requested (slots >= cnt re-read whatever id the lane holds: entry of this batch or 0 = row 0,
+        // always a valid row) and only the first cnt are consumed
+        gather_batch<GB>(my_src, my_w, rsrc, voff0, w, x, std::make_integer_sequence<int, GB>{});
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             if (u < cnt) {

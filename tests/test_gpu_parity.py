@@ -297,6 +297,29 @@ def test_engine_rng_and_call_order_errors():
         e.Loop(_device_graph(g), e.Mlp(ou['weights'], ou['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 8, 5, 0.01)
 
 
+def test_rccl_path_single_rank():
+    """The multi-GPU code path (lazy librccl load, ncclCommInitRank, grouped all-gather of state rows + flag block after
+    every body, allreduce-max used by bench.py) with a 1-rank communicator: must not change a bit."""
+    e = _engine()
+    rng = np.random.default_rng(12)
+    g, st, ou, s0 = _case(rng, n=1500, d=64, hidden=(128, 128), gain=0.6)
+    comm = e.Comm(e.Comm.unique_id(), 0, 1, 0)
+    assert comm.allreduce_max(3.5) == 3.5
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    res = []
+    for c in (None, comm):
+        for impl in (1, 0):
+            loop = e.Loop(_device_graph(g), mst, mou, 64, 30, 0.01, c)
+            loop.set_impl(impl)
+            loop.set_state0(s0)
+            res.append((loop.run(), loop.state(), loop.output()))
+            loop.close()
+    kc, sc, oc = corc.loop_node(g, st, ou, 64, 30, 0.01, s0)
+    for k, s, o in res:
+        assert k == kc and np.array_equal(s, sc) and np.array_equal(o, oc)
+    comm.close()
+
+
 def test_full_size_properties():
     """BASELINE config 3 size (1M nodes / ~10M arcs, D=64, 135->128->128->64): properties that do not need the oracle on
     the full graph: sampled rows of one step against NumPy float64, run-to-run determinism, fused == unfused bit for bit."""
