@@ -70,6 +70,7 @@ __device__ __forceinline__ float gnn_act(float v, int act)
 #define GNN_FLAG_SLOTS 16
 #define GNN_FLAG_STRIDE 32
 #define GNN_FLAG_WORDS (GNN_FLAG_SLOTS * GNN_FLAG_STRIDE)   // ints per (iteration, rank)
+#define GNN_BODY_CHUNK 16
 
 __device__ __forceinline__ bool gnn_gate_open(const int *gate, int world)
 {
@@ -147,6 +148,11 @@ struct gnn_loop {
     int kfinal = -1;
     bool have_state0 = false, ran = false;
     int impl_req = 1, impl_used = 0;
+    int32_t *ng_ip = nullptr, *ng_node = nullptr;   // cached NodeGraph^T (graph readout)
+    float *ng_w = nullptr, *ng_out = nullptr;
+    std::vector<int32_t> ng_key;
+    std::vector<float> ng_w_host;
+    int *gate_host = nullptr;               // pinned copy of one gate (early-exit check every GNN_BODY_CHUNK bodies)
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_total[2] = {nullptr, nullptr};

@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -750,8 +751,9 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS);
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 1);
-    if (!rc) rc = dev_alloc(&l->tile_ctr, (size_t)max_iter + 1);
+    if (!rc) rc = dev_alloc(&l->tile_ctr, ((size_t)max_iter + 1 + 3) & ~(size_t)3);
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
+    if (!rc && hipHostMalloc((void **)&l->gate_host, sizeof(int) * (size_t)world * GNN_FLAG_WORDS) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
     if (!rc) rc = dev_alloc(&l->out, (size_t)g->n_masked * l->T);
     for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], (size_t)g->n_masked * maxw_o);
@@ -861,31 +863,17 @@ static int unfused_iteration(gnn_loop *l, int k)
     return GNN_OK;
 }
 
-extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
+// Everything one Loop puts on the stream between the first condition and net_output.  Bodies are enqueued without waiting
+// for each other; every GNN_BODY_CHUNK bodies the gate of the next body is copied to the host and checked, so that a loop
+// that converged does not pay for max_iteration - k empty launches (about 3 us each).
+static int loop_enqueue(gnn_loop *l, bool fused)
 {
-    ARGCHK(l, "loop is NULL");
-    if (training) return gnn_fail(GNN_ERR_UNSUPPORTED, "training=True (backward through the loop) is not implemented on the device yet");
-    if (!l->have_state0) {
-        if (l->D == 0) l->have_state0 = true;
-        else return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
-    }
-    HIPCHK(hipSetDevice(l->device));
     gnn_graph *g = l->g;
     const int P = l->world;
     hipStream_t st = l->stream;
-    const bool fused = l->impl_req == 1 && gnn_fused_supported(l);
-    l->impl_used = fused ? 1 : 0;
-    int rc = fused ? gnn_fused_prepare(l) : loop_ensure_unfused(l);
-    if (rc) return rc;
-    if (l->profiling && (int)l->ev.size() < 2 * l->max_iter) {
-        const size_t old = l->ev.size();
-        l->ev.resize(2 * (size_t)l->max_iter);
-        for (size_t i = old; i < l->ev.size(); ++i) HIPCHK(hipEventCreate(&l->ev[i]));
-    }
-
-    HIPCHK(hipEventRecord(l->ev_total[0], st));
+    int rc = 0;
     HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P * GNN_FLAG_WORDS, st));
-    HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * (size_t)(l->max_iter + 1), st));
+    HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * (((size_t)l->max_iter + 1 + 3) & ~(size_t)3), st));
     float *own0 = l->state[0] + (size_t)g->row_begin * l->Ds;
     if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
         HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->row_begin * g->NL,
@@ -918,6 +906,15 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
         if (rc) return rc;
         if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k + 1], st));
         if ((rc = loop_allgather(l, l->state[(k & 1) ^ 1], l->flags + (size_t)(k + 1) * P * GNN_FLAG_WORDS))) return rc;
+        if ((k + 1) % GNN_BODY_CHUNK == 0 && k + 1 < l->max_iter) {
+            // every rank reads the same all-gathered gate, so all ranks stop at the same body
+            const size_t words = (size_t)P * GNN_FLAG_WORDS;
+            HIPCHK(hipMemcpyAsync(l->gate_host, l->flags + (size_t)(k + 1) * words, sizeof(int) * words, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            int any = 0;
+            for (size_t i = 0; i < words; i += GNN_FLAG_STRIDE) any |= l->gate_host[i];
+            if (!any) break;
+        }
     }
     hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, P, l->max_iter, l->kfinal_dev);
     HIPCHK(hipGetLastError());
@@ -932,6 +929,33 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
         rc = launch_mlp(st, l->ou, g->n_masked, l->feats, l->wf, l->out, l->T, l->otmp[0], l->otmp[1], nullptr, 1);
         if (rc) return rc;
     }
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
+{
+    ARGCHK(l, "loop is NULL");
+    if (training) return gnn_fail(GNN_ERR_UNSUPPORTED, "training=True (backward through the loop) is not implemented on the device yet");
+    if (!l->have_state0) {
+        if (l->D == 0) l->have_state0 = true;
+        else return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
+    }
+    HIPCHK(hipSetDevice(l->device));
+    gnn_graph *g = l->g;
+    const int P = l->world;
+    hipStream_t st = l->stream;
+    const bool fused = l->impl_req == 1 && gnn_fused_supported(l);
+    l->impl_used = fused ? 1 : 0;
+    int rc = fused ? gnn_fused_prepare(l) : loop_ensure_unfused(l);
+    if (rc) return rc;
+    if (l->profiling && (int)l->ev.size() < 2 * l->max_iter) {
+        const size_t old = l->ev.size();
+        l->ev.resize(2 * (size_t)l->max_iter);
+        for (size_t i = old; i < l->ev.size(); ++i) HIPCHK(hipEventCreate(&l->ev[i]));
+    }
+
+    HIPCHK(hipEventRecord(l->ev_total[0], st));
+    if ((rc = loop_enqueue(l, fused))) return rc;
     HIPCHK(hipEventRecord(l->ev_total[1], st));
     HIPCHK(hipStreamSynchronize(st));
     l->kfinal = *l->kfinal_host;
@@ -986,21 +1010,30 @@ extern "C" int gnn_loop_readout(const gnn_loop *l, int G, const int32_t *ng_indp
         ARGCHK(ng_node[e] >= 0 && ng_node[e] < l->g->n_masked, "NodeGraph row %d but only %lld output rows (masks must be all-true for graph-based problems)",
                ng_node[e], (long long)l->g->n_masked);
     HIPCHK(hipSetDevice(l->device));
-    int32_t *dip = nullptr, *dn = nullptr;
-    float *dw = nullptr, *dout = nullptr;
-    int rc = dev_upload(&dip, ng_indptr, (size_t)G + 1);
-    if (!rc) rc = dev_upload(&dn, ng_node, (size_t)nnz);
-    if (!rc) rc = dev_upload(&dw, ng_w, (size_t)nnz);
-    if (!rc) rc = dev_alloc(&dout, (size_t)G * l->T);
-    if (!rc) {
-        hipLaunchKernelGGL(k_readout, cdiv((int64_t)G * l->T, 64), 64, 0, l->stream, G, l->T, dip, dn, dw, l->out, dout);
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(out_graph, dout, sizeof(float) * (size_t)G * l->T, hipMemcpyDeviceToHost, l->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
-        if (e != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "readout: %s", hipGetErrorString(e));
+    // NodeGraph^T rarely changes between calls on the same loop: keep it on the device and re-upload only when it differs
+    gnn_loop *lm = const_cast<gnn_loop *>(l);
+    std::vector<int32_t> key(ng_indptr, ng_indptr + G + 1);
+    key.insert(key.end(), ng_node, ng_node + nnz);
+    const bool same = lm->ng_key == key && lm->ng_w_host.size() == (size_t)nnz &&
+                      (nnz == 0 || memcmp(lm->ng_w_host.data(), ng_w, sizeof(float) * nnz) == 0);
+    int rc = GNN_OK;
+    if (!same) {
+        (void)hipFree(lm->ng_ip); (void)hipFree(lm->ng_node); (void)hipFree(lm->ng_w); (void)hipFree(lm->ng_out);
+        lm->ng_ip = lm->ng_node = nullptr; lm->ng_w = lm->ng_out = nullptr;
+        lm->ng_key.clear();
+        rc = dev_upload(&lm->ng_ip, ng_indptr, (size_t)G + 1);
+        if (!rc) rc = dev_upload(&lm->ng_node, ng_node, (size_t)nnz);
+        if (!rc) rc = dev_upload(&lm->ng_w, ng_w, (size_t)nnz);
+        if (!rc) rc = dev_alloc(&lm->ng_out, (size_t)G * l->T);
+        if (rc) return rc;
+        lm->ng_key = key;
+        lm->ng_w_host.assign(ng_w, ng_w + nnz);
     }
-    (void)hipFree(dip); (void)hipFree(dn); (void)hipFree(dw); (void)hipFree(dout);
-    return rc;
+    hipLaunchKernelGGL(k_readout, cdiv((int64_t)G * l->T, 64), 64, 0, l->stream, G, l->T, lm->ng_ip, lm->ng_node, lm->ng_w, l->out, lm->ng_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_graph, lm->ng_out, sizeof(float) * (size_t)G * l->T, hipMemcpyDeviceToHost, l->stream));
+    HIPCHK(hipStreamSynchronize(l->stream));
+    return GNN_OK;
 }
 
 extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output)
@@ -1032,6 +1065,8 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     if (l->kfinal_host) (void)hipHostFree(l->kfinal_host);
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
+    if (l->gate_host) (void)hipHostFree(l->gate_host);
+    (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
     delete l;
     return GNN_OK;

@@ -318,7 +318,31 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // gather: groups of lpr lanes, one node per group per pass, one column chunk per lane (lpr * vec >= Ds)
+    if (Ds <= 32) {
+        // narrow rows (small label-sized states): lane = (node, column half); all 32 nodes walk their entries at once, so
+        // the latency chain is max-degree long instead of 32 / groups passes long
+        const int node = lane & 31, hf = lane >> 5;
+        const int cbeg = hf ? (Ds + 1) / 2 : 0, cend = hf ? Ds : (Ds + 1) / 2;
+        const int beg = ipt[node], end = ipt[node + 1];
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+        for (int e = beg; e < end; ++e) {
+            const float w = gload1(a.adj_w + e);
+            const float *xp = a.state_cur + (int64_t)gload1(a.adj_src + e) * Ds + cbeg;
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (cbeg + c < cend) acc[c] = __builtin_fmaf(w, gload1(xp + c), acc[c]);
+        }
+        if (node < nvalid) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (cbeg + c < cend) X[node * KP + c_aggs + cbeg + c] = acc[c];
+        }
+        return;
+    }
+    // gather: groups of lpr lanes, one node per group per pass, one column chunk per lane (lpr * vec >= Ds); the entries
+    // of a row are consumed four at a time (ids, weights and rows of the four requested before the first fmaf)
     const int lpr = a.lpr, gl = lane & (lpr - 1), grp = lane >> a.lpr_log2, groups = 64 >> a.lpr_log2;
     const bool colok = gl * a.vec < Ds;
     const int c0 = colok ? gl * a.vec : 0;
@@ -326,15 +350,26 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
         const int i = pass * groups + grp;                 // < 32 because groups divides 32 (lpr >= 2)
         const int beg = ipt[i], end = ipt[i + 1];          // rows past nvalid: beg == end
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int e = beg; e < end; ++e) {
-            const float w = gload1(a.adj_w + e);
-            const float *xp = a.state_cur + (int64_t)gload1(a.adj_src + e) * Ds + c0;
-            if (a.vec == 4) {
-                const v4f v = gload4(xp);
-                acc[0] = __builtin_fmaf(w, v.x, acc[0]); acc[1] = __builtin_fmaf(w, v.y, acc[1]);
-                acc[2] = __builtin_fmaf(w, v.z, acc[2]); acc[3] = __builtin_fmaf(w, v.w, acc[3]);
-            } else {
-                acc[0] = __builtin_fmaf(w, gload1(xp), acc[0]);
+        for (int e = beg; e < end; e += 4) {
+            float w[4];
+            v4f x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u < end ? e + u : e;    // clamp: a real entry, result unused
+                w[u] = gload1(a.adj_w + ee);
+                const float *xp = a.state_cur + (int64_t)gload1(a.adj_src + ee) * Ds + c0;
+                if (a.vec == 4) x[u] = gload4(xp);
+                else x[u] = v4f{gload1(xp), 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e + u < end) {
+                    acc[0] = __builtin_fmaf(w[u], x[u].x, acc[0]);
+                    if (a.vec == 4) {
+                        acc[1] = __builtin_fmaf(w[u], x[u].y, acc[1]); acc[2] = __builtin_fmaf(w[u], x[u].z, acc[2]);
+                        acc[3] = __builtin_fmaf(w[u], x[u].w, acc[3]);
+                    }
+                }
             }
         }
         if (i < nvalid && colok) {
