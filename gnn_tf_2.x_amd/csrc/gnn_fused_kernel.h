@@ -57,7 +57,7 @@ __device__ __forceinline__ int shfl_i(int v, int src_lane) { return __builtin_am
 template <int J>
 __device__ __forceinline__ int row_bcast_i(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true);   // bound_ctrl: no "old" value to materialise
 }
 template <int J>
 __device__ __forceinline__ float row_bcast_f(float v) { return __int_as_float(row_bcast_i<J>(__float_as_int(v))); }
