@@ -120,10 +120,23 @@ class GNNnodeBased(BaseClass):
 
 
 class GNNedgeBased(GNNnodeBased):
-    """GNN for edge-based problems.  The per-arc readout (reference GNN.py:289-302) is not on the device yet."""
+    """GNN for edge-based problems: node-based state loop, then net_output on [state(i0) | state(i1) | arc label] of the
+    arcs selected by set_mask & output_mask (reference GNN.py:286-302; the pairing of index pairs and arc labels by position
+    is the reference's)."""
 
-    def Loop(self, g, *, training: bool = False, state0=None):
-        raise NotImplementedError('GNNedgeBased: the arc-state readout (reference GNN.py:289-302) is not implemented on the MI355X engine yet')
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        if training:
+            raise NotImplementedError('Loop(training=True) is not implemented on the MI355X engine yet')
+        dev = g.device_graph(self.device)
+        loop = self._device_loop(dev)
+        if not getattr(loop, '_edge_ready', False):
+            loop.set_edge_readout(*g.edge_readout_arrays())
+            loop._edge_ready = True
+        if self.state_vect_dim > 0:
+            loop.set_state0(state0, self.seed)
+        k = loop.run(False)
+        return k, loop.state(), loop.output()
 
 
 class GNNgraphBased(GNNnodeBased):

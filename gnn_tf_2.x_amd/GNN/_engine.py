@@ -17,7 +17,7 @@ ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 's
 EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create',
            'gnn_graph_derive', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
-           'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout',
+           'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout',
            'gnn_loop_set_impl', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy']
 
@@ -262,6 +262,16 @@ class Loop:
         if state0 is not None:
             state0 = _f32(state0, (self.n_rows, self.Ds))
         _check(lib().gnn_loop_set_state0(self._h, _fp(state0), C.c_uint64(seed)))
+
+    def set_edge_readout(self, entry_dst, arc_labels, arc_mask):
+        """Switch to the per-arc readout of GNNedgeBased (reference GNN.py:289-302)."""
+        entry_dst = np.ascontiguousarray(entry_dst, dtype=np.int32)
+        arc_labels = _f32(arc_labels)
+        arc_mask = np.ascontiguousarray(arc_mask, dtype=np.uint8)
+        if not (len(entry_dst) == len(arc_mask) == arc_labels.shape[0]):
+            raise ValueError('entry_dst, arc_labels and arc_mask must have one row per arc')
+        _check(lib().gnn_loop_set_edge_readout(self._h, _ip(entry_dst), _fp(arc_labels), arc_mask.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self.n_masked = int(arc_mask.sum())
 
     def set_impl(self, impl: int) -> int:
         used = C.c_int(0)

@@ -238,11 +238,21 @@ class GraphTensor:
             indptr, adj_src, adj_w = self.Adjacency
             _, arc_id, arc_w = self.ArcNode
             mask = self.loop_mask()
-            if len(mask) != self.nodes.shape[0]:
-                raise NotImplementedError('arc-based masks (edge-based GNN) are not supported by the device engine yet')
+            if len(mask) != self.nodes.shape[0]:       # arc-based problem: the node mask is unused by the per-arc readout
+                mask = np.ones(self.nodes.shape[0], dtype=bool)
             self._device_graph = _engine.Graph(self.nodes.shape[0], indptr, adj_src, adj_w, arc_w,
                                                self.arcs[:, 2:][arc_id], self.nodes, mask, device=device)
         return self._device_graph
+
+    def edge_readout_arrays(self):
+        """Inputs of gnn_loop_set_edge_readout: CSR row (destination) of every Adjacency^T entry, the arc labels in ORIGINAL
+        arc order, and set_mask & output_mask over arcs (reference GNN.py:289-302 pairs entries and arcs by position)."""
+        indptr = self.Adjacency[0]
+        entry_dst = np.repeat(np.arange(len(indptr) - 1, dtype=np.int32), np.diff(indptr))
+        mask = self.loop_mask()
+        if len(mask) != self.arcs.shape[0]:
+            raise ValueError('edge-based GNN needs set_mask / output_mask over the arcs (problem_based == \'a\')')
+        return entry_dst, self.arcs[:, 2:], mask
 
     def nodegraph_csr(self):
         """NodeGraph^T as CSR over graphs, ascending node inside a graph (input of gnn_loop_readout)."""

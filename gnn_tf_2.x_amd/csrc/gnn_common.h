@@ -152,6 +152,11 @@ struct gnn_loop {
     float *ng_w = nullptr, *ng_out = nullptr;
     std::vector<int32_t> ng_key;
     std::vector<float> ng_w_host;
+    // edge-based readout (GNNedgeBased.apply_filters): entry -> CSR row, arc labels in original order, masked arc list
+    bool edge_mode = false, edge_expected = false;
+    int32_t *edge_dst = nullptr, *edge_rows = nullptr;
+    float *edge_labels = nullptr;
+    int64_t n_edge_masked = 0;
     int *gate_host = nullptr;               // pinned copy of one gate (early-exit check every GNN_BODY_CHUNK bodies)
     bool profiling = false;
     std::vector<hipEvent_t> ev;

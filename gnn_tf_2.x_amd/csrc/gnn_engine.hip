@@ -276,6 +276,30 @@ __global__ void k_feats(int64_t n_masked, const int32_t *__restrict__ masked_row
     feats[t] = c < Ds ? state[row * Ds + c] : nodes_own[row * NL + (c - Ds)];
 }
 
+// GNNedgeBased.apply_filters(): feats[m] = [F[dst(e)] | F[src(e)] | arc_labels[e]], e = m-th masked arc, F = [state | nodes?]
+__global__ void k_feats_edge(int64_t n_masked, const int32_t *__restrict__ rows, const int32_t *__restrict__ entry_dst,
+                             const int32_t *__restrict__ adj_src, const float *s0, const float *s1, const int *kfinal, int Ds,
+                             const float *__restrict__ nodes, int NL, int NLc, const float *__restrict__ arc_labels, int AL,
+                             float *__restrict__ feats)
+{
+    const int wn = Ds + NLc, wf = 2 * wn + AL;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_masked * wf) return;
+    const float *state = ((*kfinal) & 1) ? s1 : s0;
+    const int64_t m = t / wf;
+    int c = (int)(t - m * wf);
+    const int64_t e = rows[m];
+    float v;
+    if (c < 2 * wn) {
+        const int64_t node = c < wn ? entry_dst[e] : adj_src[e];
+        if (c >= wn) c -= wn;
+        v = c < Ds ? state[node * Ds + c] : nodes[node * NL + (c - Ds)];
+    } else {
+        v = arc_labels[e * AL + (c - 2 * wn)];
+    }
+    feats[t] = v;
+}
+
 // graph readout: out_graph[g, t] = sum over the stored (node, w) of graph g, ascending node, fmaf(w, out_nodes[node, t])
 __global__ void k_readout(int G, int T, const int32_t *__restrict__ indptr, const int32_t *__restrict__ node,
                           const float *__restrict__ w, const float *__restrict__ out_nodes, float *__restrict__ out_graph)
@@ -721,7 +745,9 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     const int in_s = Ds + NLc + Ds + NLc + g->AL;                              // GNN/MLP.py:104
     ARGCHK(net_state->dims[0] == in_s, "net_state input width %d != AL + 2*(NL + D) = %d", net_state->dims[0], in_s);
     ARGCHK(net_state->dims.back() == Ds, "net_state output width %d != state width %d", net_state->dims.back(), Ds);
-    ARGCHK(net_output->dims[0] == Ds + NLc, "net_output input width %d != NL + D = %d", net_output->dims[0], Ds + NLc);
+    const bool edge_width = net_output->dims[0] == 2 * (Ds + NLc) + g->AL && net_output->dims[0] != Ds + NLc;
+    ARGCHK(net_output->dims[0] == Ds + NLc || edge_width, "net_output input width %d is neither NL + D = %d (node/graph based) nor 2 (NL + D) + AL = %d (edge based)",
+           net_output->dims[0], Ds + NLc, 2 * (Ds + NLc) + g->AL);
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
     int64_t rb = 0, nr = 0;
     gnn_shard_range(g->N, rank, world, &rb, &nr);
@@ -734,6 +760,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     l->g = g; l->st = net_state; l->ou = net_output; l->comm = comm; l->device = g->device; l->rank = rank; l->world = world;
     l->D = state_dim; l->Ds = Ds; l->NLc = NLc; l->in_s = in_s; l->wf = Ds + NLc; l->T = net_output->dims.back();
     l->max_iter = max_iter; l->thr = threshold;
+    l->edge_expected = edge_width;
     l->shard_rows = ((g->N + world - 1) / world + 31) / 32 * 32;
     l->N_pad = l->shard_rows * world;
     int rc = 0;
@@ -754,9 +781,11 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     if (!rc) rc = dev_alloc(&l->tile_ctr, ((size_t)max_iter + 1 + 3) & ~(size_t)3);
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc && hipHostMalloc((void **)&l->gate_host, sizeof(int) * (size_t)world * GNN_FLAG_WORDS) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
-    if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
-    if (!rc) rc = dev_alloc(&l->out, (size_t)g->n_masked * l->T);
-    for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], (size_t)g->n_masked * maxw_o);
+    if (!edge_width) {      // the edge-based buffers are sized in gnn_loop_set_edge_readout
+        if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
+        if (!rc) rc = dev_alloc(&l->out, (size_t)g->n_masked * l->T);
+        for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], (size_t)g->n_masked * maxw_o);
+    }
     if (!rc && hipEventCreate(&l->ev_total[0]) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipEventCreate");
     if (!rc && hipEventCreate(&l->ev_total[1]) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipEventCreate");
     if (rc) { gnn_loop_destroy(l); return rc; }
@@ -920,6 +949,18 @@ static int loop_enqueue(gnn_loop *l, bool fused)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
 
+    if (l->edge_mode) {      // GNNedgeBased.apply_filters + net_output on the masked arcs (GNN.py:289-302, :279)
+        if (l->n_edge_masked) {
+            const int we = l->ou->dims[0];
+            const int64_t tot = l->n_edge_masked * we;
+            hipLaunchKernelGGL(k_feats_edge, cdiv(tot, 256), 256, 0, st, l->n_edge_masked, l->edge_rows, l->edge_dst, g->sh->adj_src, l->state[0],
+                               l->state[1], l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, l->edge_labels, g->AL, l->feats);
+            HIPCHK(hipGetLastError());
+            rc = launch_mlp(st, l->ou, l->n_edge_masked, l->feats, we, l->out, l->T, l->otmp[0], l->otmp[1], nullptr, 1);
+            if (rc) return rc;
+        }
+        return GNN_OK;
+    }
     // apply_filters + net_output on the owned masked rows (GNN.py:275-279)
     if (g->n_masked) {
         const int64_t tot = g->n_masked * l->wf;
@@ -940,6 +981,8 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
         if (l->D == 0) l->have_state0 = true;
         else return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
     }
+    if (l->edge_expected && !l->edge_mode)
+        return gnn_fail(GNN_ERR_STATE, "net_output has the edge-based input width: call gnn_loop_set_edge_readout first");
     HIPCHK(hipSetDevice(l->device));
     gnn_graph *g = l->g;
     const int P = l->world;
@@ -991,11 +1034,43 @@ extern "C" int gnn_loop_get_output(const gnn_loop *l, float *out, int64_t *n_mas
 {
     ARGCHK(l, "loop is NULL");
     if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
-    if (n_masked) *n_masked = l->g->n_masked;
-    if (out && l->g->n_masked) {
+    const int64_t m = l->edge_mode ? l->n_edge_masked : l->g->n_masked;
+    if (n_masked) *n_masked = m;
+    if (out && m) {
         HIPCHK(hipSetDevice(l->device));
-        HIPCHK(hipMemcpy(out, l->out, sizeof(float) * (size_t)l->g->n_masked * l->T, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, l->out, sizeof(float) * (size_t)m * l->T, hipMemcpyDeviceToHost));
     }
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, const float *arc_labels, const uint8_t *arc_mask)
+{
+    ARGCHK(l && (l->g->E == 0 || (entry_dst && arc_mask && (arc_labels || l->g->AL == 0))), "bad arguments");
+    ARGCHK(l->edge_expected, "net_output input width %d is not the edge-based 2 (NL + D) + AL", l->ou->dims[0]);
+    ARGCHK(l->world == 1 && l->g->n_rows == l->g->N, "the edge-based readout is single-GPU only");
+    const gnn_graph *g = l->g;
+    std::vector<int32_t> rows;
+    for (int64_t e = 0; e < g->E; ++e) {
+        ARGCHK(entry_dst[e] >= 0 && entry_dst[e] < g->N, "entry_dst[%lld]=%d outside [0,%lld)", (long long)e, entry_dst[e], (long long)g->N);
+        if (arc_mask[e]) rows.push_back((int32_t)e);
+    }
+    HIPCHK(hipSetDevice(l->device));
+    (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels);
+    (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->otmp[0]); (void)hipFree(l->otmp[1]);
+    l->feats = l->out = l->otmp[0] = l->otmp[1] = nullptr;
+    l->edge_dst = l->edge_rows = nullptr; l->edge_labels = nullptr;
+    l->n_edge_masked = (int64_t)rows.size();
+    int maxw_o = 1;
+    for (int i = 1; i <= l->ou->n_layers; ++i) maxw_o = std::max(maxw_o, l->ou->dims[i]);
+    int rc = dev_upload(&l->edge_dst, entry_dst, (size_t)g->E);
+    if (!rc) rc = dev_upload(&l->edge_rows, rows.data(), rows.size());
+    if (!rc) rc = dev_upload(&l->edge_labels, arc_labels, (size_t)g->E * g->AL);
+    if (!rc) rc = dev_alloc(&l->feats, rows.size() * (size_t)l->ou->dims[0]);
+    if (!rc) rc = dev_alloc(&l->out, rows.size() * (size_t)l->T);
+    for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], rows.size() * (size_t)maxw_o);
+    if (rc) return rc;
+    l->edge_mode = true;
+    l->ran = false;
     return GNN_OK;
 }
 
@@ -1066,6 +1141,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
     if (l->gate_host) (void)hipHostFree(l->gate_host);
+    (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels);
     (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
     delete l;

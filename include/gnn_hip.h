@@ -105,6 +105,13 @@ int gnn_loop_get_output(const gnn_loop *l, float *out /* [n_masked, T] */, int64
  * NodeGraph^T is passed in CSR form over graphs: ng_indptr[G+1], ng_node (ascending), ng_w. */
 int gnn_loop_readout(const gnn_loop *l, int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node,
                      const float *ng_w, float *out_graph /* [G, T] */);
+/* GNNedgeBased.apply_filters (GNN/GNN.py:289-302): switches the output stage of this loop to the per-arc readout.  Row e of
+ * the readout is [F[i0(e)] | F[i1(e)] | arc_labels[e]] with F = [state | nodes (iff state_dim > 0)], (i0, i1) the e-th index
+ * pair of the transposed, reordered Adjacency (i0 = entry_dst[e], the CSR row of entry e; i1 = adj_src[e]) and arc_labels in
+ * ORIGINAL arc order: the reference pairs the two by position (consistent for symmetric, lexicographically sorted arc
+ * lists; SURVEY.md 8a quirk 6, reproduced as is).  arc_mask = set_mask & output_mask over arcs.  net_output must take
+ * 2 (NL [D>0] + Ds) + AL inputs (GNN/MLP.py:109).  Single GPU only. */
+int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, const float *arc_labels, const uint8_t *arc_mask);
 /* selects the implementation: 0 = unfused reference kernels (one kernel per TF op), 1 = fused gather+MLP kernel
  * when the shapes allow it (default), falling back to 0 otherwise.  *used (may be NULL) reports the choice. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);

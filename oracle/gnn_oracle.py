@@ -276,6 +276,18 @@ def loop_node(g: dict, net_state: dict, net_output: dict, state_vect_dim: int, m
     return float(k), state, out
 
 
+def edge_features(g: dict, state: np.ndarray, state_vect_dim: int, dtype=np.float32) -> np.ndarray:
+    """GNNedgeBased.apply_filters.  Follows GNN/GNN.py:289-302: rows of [state | nodes?] gathered by the index pairs of the
+    transposed, reordered Adjacency (:294-295), concatenated with arcs[:, 2:] in arc order (:299), masked by the arc mask."""
+    nodes = np.asarray(g['nodes'], dtype=dtype)
+    feats = state if not state_vect_dim else np.concatenate([state, nodes], axis=1)      # :291
+    indptr, src, _ = g['adjT']
+    dst = np.repeat(np.arange(len(indptr) - 1), np.diff(indptr))
+    pair = np.concatenate([feats[dst], feats[src]], axis=1)                             # :294-295 ([E, 2, F] -> [E, 2F])
+    arc_state = np.concatenate([pair, np.asarray(g['arcs'], dtype=dtype)[:, 2:]], axis=1)   # :299
+    return arc_state[np.logical_and(g['set_mask'], g['output_mask'])]                   # :302
+
+
 def loop_graph(g: dict, net_state, net_output, state_vect_dim, max_iteration, threshold, state0=None, dtype=np.float32):
     """GNNgraphBased.Loop.  Follows GNN/GNN.py:318-333: node-based Loop, then NodeGraph^T @ out_nodes (:331-332)."""
     if g.get('NodeGraph') is None:

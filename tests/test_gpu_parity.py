@@ -196,6 +196,42 @@ def test_graph_based_readout_and_errors():
         _models(st, make_mlp(rng, nl + 1, [2], 'softmax'), 0, 5, 0.01, GNNnodeBased).Loop(go)   # wrong net_output width
 
 
+@pytest.mark.parametrize('d', [0, 6])
+def test_edge_based_readout(d):
+    """GNNedgeBased.Loop (reference GNN.py:286-302): per-arc readout [F(i0) | F(i1) | arc label] through set/output masks
+    over the arcs, against the oracle (states from the C oracle, readout rows per the reference, net_output by the C oracle)."""
+    from GNN.GNN import GNNedgeBased
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(40 + d)
+    n, nl, al = 300, 3, 2
+    arcs = random_arcs(rng, n, 900, al)                      # symmetric, lexicographically sorted (the consistent case)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    e = len(arcs)
+    set_mask, output_mask = rng.random(e) < 0.8, rng.random(e) < 0.7
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=np.zeros((int(output_mask.sum()), 2)), problem_based='a',   # one target per output_mask arc
+                     set_mask=set_mask, output_mask=output_mask)
+    ins, ls = orc.get_inout_dims('state', nl, al, 2, 'a', d, [12])
+    ino, lo = orc.get_inout_dims('output', nl, al, 2, 'a', d, None)
+    ds, nlc = (d if d else nl), (nl if d else 0)
+    assert ino == 2 * (ds + nlc) + al
+    st, ou = make_mlp(rng, ins, ls, 'tanh', gain=0.6), make_mlp(rng, ino, lo, 'softmax')
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32) if d else None
+    gnn = _models(st, ou, d, 20, 0.01, GNNedgeBased)
+    k, s, o = gnn.Loop(go, state0=s0)
+    gd = orc.make_graph_dict(arcs, nodes, 'average')
+    node_out = make_mlp(rng, ds + nlc, [2], 'softmax')       # only to satisfy the node-based oracle signature
+    kc, sc, _ = corc.loop_node(gd, st, node_out, d, 20, 0.01, s0, want_out=False)
+    gd['set_mask'], gd['output_mask'] = set_mask, output_mask
+    feats = orc.edge_features(gd, sc, d)
+    oc = corc.mlp_forward(feats, ou['weights'], ou['activations'], True)
+    assert k == kc and np.array_equal(s, sc)
+    assert o.shape == oc.shape == (int((set_mask & output_mask).sum()), 2) and np.array_equal(o, oc)
+    it, loss, targs, out = gnn.evaluate_single_graph(go, training=False)
+    assert targs.shape == out.shape
+    k2, s2, o2 = gnn.Loop(go, state0=s0)                      # cached loop, second call
+    assert k2 == k and np.array_equal(o2, o)
+
+
 def test_mutag_batches_graph_based():
     """BASELINE config 2: MUTAG batches of 32 graphs, graph-based, state = node labels (14), net_state 31 -> [32, 32, 14],
     max_iteration 50: k, states and graph outputs against the C oracle; LGNN on the same batch."""
