@@ -1,0 +1,87 @@
+"""The training oracle (one training step: unrolled-loop back-propagation) against central finite differences in float64.
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import gnn_oracle as orc
+from oracle import gnn_train_oracle as tro
+from util import make_mlp, random_arcs
+
+
+def _case(rng, d, graph_based=False, act='tanh'):
+    n, nl, al = 40, 3, 2
+    arcs = random_arcs(rng, n, 90, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    ng = None
+    if graph_based:
+        ng = np.zeros((n, 2), np.float32); ng[:25, 0] = 1 / 25; ng[25:, 1] = 1 / 15
+    g = orc.make_graph_dict(arcs, nodes, 'average', NodeGraph=ng)
+    if not graph_based:
+        g['set_mask'] = rng.random(n) < 0.8
+    ds, nlc = (d if d else nl), (nl if d else 0)
+    st = make_mlp(rng, al + 2 * (ds + nlc), [7, ds], act, gain=0.8, bn_random=True)
+    ou = make_mlp(rng, ds + nlc, [5, 2], 'softmax' if False else act, out_activation='softmax', bn_random=True)
+    st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1, 1: 0.3}
+    m = n if graph_based else int(np.sum(g['set_mask'] & g['output_mask']))
+    masks_s = [{0: (rng.random((n, st['weights'][0].shape[0])) > 0.2)} for _ in range(6)]
+    masks_o = {0: rng.random((m, ds + nlc)) > 0.1, 1: rng.random((m, 5)) > 0.3}
+    n_t = 2 if graph_based else m
+    targets = np.eye(2)[rng.integers(0, 2, n_t)]
+    weights = rng.uniform(0.5, 1.5, n_t)
+    s0 = 0.1 * rng.standard_normal((n, ds)) if d else None
+    return g, st, ou, s0, masks_s, masks_o, targets, weights
+
+
+@pytest.mark.parametrize('d,graph_based,act,loss', [(4, False, 'tanh', 'categorical_crossentropy'), (0, False, 'selu', 'categorical_crossentropy'),
+                                                      (3, True, 'sigmoid', 'mean_squared_error'), (0, True, 'relu', 'categorical_crossentropy')])
+def test_gradients_match_finite_differences(d, graph_based, act, loss):
+    rng = np.random.default_rng(3 + d)
+    g, st, ou, s0, ms, mo, targets, weights = _case(rng, d, graph_based, act)
+    # threshold 0 => exactly max_iteration bodies, so that the iteration count cannot flip under the perturbation
+    kw = dict(state_vect_dim=d, max_iteration=4, threshold=0.0, state0=s0, masks_state=ms, masks_output=mo, targets=targets,
+              sample_weights=weights, loss=loss, mean=False, graph_based=graph_based)
+    res = tro.train_step(g, st, ou, **kw)
+    assert res['k'] == 4 and np.isfinite(res['loss'])
+    eps = 1e-6
+    for net, grads in ((st, res['grads_state']), (ou, res['grads_output'])):
+        n_tr = len(grads)
+        for wi in range(n_tr):
+            w = net['weights'][wi] = np.asarray(net['weights'][wi], np.float64)
+            for _ in range(3):
+                idx = tuple(rng.integers(0, s) for s in w.shape)
+                old = w[idx]
+                w[idx] = old + eps; lp = tro.train_step(g, st, ou, **kw)['loss']
+                w[idx] = old - eps; lm = tro.train_step(g, st, ou, **kw)['loss']
+                w[idx] = old
+                fd = (lp - lm) / (2 * eps)
+                assert abs(fd - grads[wi][idx]) <= 1e-5 * max(1.0, abs(fd)), (wi, idx, fd, grads[wi][idx])
+    # mean=True divides the net_state gradients by the iteration count (GNN_BaseClass.py:241), not the net_output ones
+    res_m = tro.train_step(g, st, ou, **dict(kw, mean=True))
+    for a, b in zip(res_m['grads_state'], res['grads_state']):
+        np.testing.assert_allclose(a, b / 4, rtol=1e-12)
+    for a, b in zip(res_m['grads_output'], res['grads_output']):
+        np.testing.assert_allclose(a, b, rtol=1e-12)
+
+
+def test_training_forward_semantics():
+    rng = np.random.default_rng(0)
+    g, st, ou, s0, ms, mo, targets, weights = _case(rng, 4)
+    # without dropout and with BatchNormalization statistics equal to the batch's, training forward == inference forward
+    x = rng.standard_normal((50, st['weights'][0].shape[0]))
+    net = dict(st, dropout={})
+    y, cache = tro.mlp_train_forward(x, net, {}, np.float64)
+    inf = dict(net, weights=list(net['weights'][:-2]) + [cache['batch_mean'], cache['batch_var']])
+    np.testing.assert_allclose(y, orc.mlp_forward(x, inf['weights'], inf['activations'], True, np.float64), atol=1e-12)
+    # dropout scales kept units by 1 / (1 - rate)
+    y2, c2 = tro.mlp_train_forward(x, dict(st, dropout={0: 0.5}, batch_normalization=False, weights=st['weights'][:-4]), {0: np.ones_like(x)}, np.float64)
+    y3 = orc.mlp_forward(2 * x, st['weights'][:-4], st['activations'], False, np.float64)
+    np.testing.assert_allclose(y2, y3, atol=1e-12)
+    # moving statistics move once per executed body
+    res = tro.train_step(g, st, ou, 4, 3, 0.0, s0, ms, mo, targets, weights)
+    assert res['k'] == 3
+    mv = np.asarray(st['weights'][-2], np.float64)
+    assert not np.allclose(res['moving_state'][0], mv)
+    # Adam: first step moves every parameter by about lr against the gradient sign
+    p, gr = [np.ones(3)], [np.array([0.5, -2.0, 1e-3])]
+    new = tro.adam_update(p, gr, [np.zeros(3)], [np.zeros(3)], 1)
+    np.testing.assert_allclose(new[0], 1 - 0.001 * np.sign(gr[0]), atol=5e-6)   # epsilon 1e-7 is not bias-corrected in Keras
