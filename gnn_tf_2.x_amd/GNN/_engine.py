@@ -17,7 +17,7 @@ ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 's
 EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create',
            'gnn_graph_derive', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
-           'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout',
+           'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_set_impl', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy']
 
@@ -272,6 +272,60 @@ class Loop:
             raise ValueError('entry_dst, arc_labels and arc_mask must have one row per arc')
         _check(lib().gnn_loop_set_edge_readout(self._h, _ip(entry_dst), _fp(arc_labels), arc_mask.ctypes.data_as(C.POINTER(C.c_uint8))))
         self.n_masked = int(arc_mask.sum())
+
+    def train_step(self, net_state: 'Mlp', net_output: 'Mlp', src_csr, targets, sample_weights, loss_kind: int, ng_csr=None,
+                   dropout_state=None, dropout_output=None, masks_state=None, masks_output=None, seed: int = 0,
+                   bn_state=None, bn_output=None, max_iter: int = 0):
+        """gnn_loop_train_step: loss, iteration count, raw gradients (lists shaped like the trainable arrays) and the
+        BatchNormalization batch statistics of every call."""
+        sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2]))
+        targets, sample_weights = _f32(targets), _f32(sample_weights)
+        ls, lo = net_state.n, net_output.n
+        ds_ = _f32(dropout_state if dropout_state is not None else np.zeros(ls + 1))
+        do_ = _f32(dropout_output if dropout_output is not None else np.zeros(lo + 1))
+
+        def shapes(net):
+            out = []
+            for l in range(net.n):
+                out += [(int(net.dims[l]), int(net.dims[l + 1])), (int(net.dims[l + 1]),)]
+            if net.batch_normalization:
+                out += [(int(net.dims[-1]),), (int(net.dims[-1]),)]
+            return out
+
+        shp_s, shp_o = shapes(net_state), shapes(net_output)
+        gs = np.zeros(sum(int(np.prod(x)) for x in shp_s), np.float32)
+        go = np.zeros(sum(int(np.prod(x)) for x in shp_o), np.float32)
+        fs, fo = int(net_state.dims[-1]), int(net_output.dims[-1])
+        bns = np.zeros((max(1, max_iter), 2, fs), np.float32)
+        bno = np.zeros((2, fo), np.float32)
+        ms = np.ascontiguousarray(masks_state, np.uint8) if masks_state is not None else None
+        mo = np.ascontiguousarray(masks_output, np.uint8) if masks_output is not None else None
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+        if ng_csr is not None:
+            ngi, ngn, ngw = np.ascontiguousarray(ng_csr[0], np.int32), np.ascontiguousarray(ng_csr[1], np.int32), _f32(ng_csr[2])
+            n_graphs = len(ngi) - 1
+        else:
+            ngi = ngn = ngw = None
+            n_graphs = 0
+        bs = _f32(bn_state) if bn_state is not None else None
+        bo = _f32(bn_output) if bn_output is not None else None
+        loss, k = C.c_float(), C.c_float()
+        _check(lib().gnn_loop_train_step(self._h, _ip(sip), _ip(sdst), _fp(sw), _fp(targets), _fp(sample_weights),
+                                         C.c_int64(targets.shape[0]), C.c_int(loss_kind), C.c_int(n_graphs), _ip(ngi), _ip(ngn), _fp(ngw),
+                                         _fp(ds_), _fp(do_), u8(ms), u8(mo), C.c_uint64(seed), _fp(bs), _fp(bo), C.byref(loss), C.byref(k),
+                                         _fp(gs), _fp(go), _fp(bns), _fp(bno)))
+
+        def split(flat, shp):
+            out, off = [], 0
+            for x in shp:
+                cnt = int(np.prod(x))
+                out.append(flat[off:off + cnt].reshape(x).copy())
+                off += cnt
+            return out
+
+        kk = int(k.value)
+        return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
+                    bn_batch_state=bns[:kk], bn_batch_output=bno)
 
     def set_impl(self, impl: int) -> int:
         used = C.c_int(0)

@@ -169,6 +169,10 @@ struct gnn_loop {
 int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const int32_t *idx, const float *w, const float *X,
                     int width, int64_t ldx, float *out, int64_t ldo, const int *gate, int world);
 
+int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float *X, int64_t ldx, const float *W, const float *b,
+                     int act, float *Y, int64_t ldy);
+int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base);
+
 // gnn_fused.hip
 bool gnn_fused_supported(const gnn_loop *l);
 int gnn_fused_prepare(gnn_loop *l);

@@ -387,6 +387,32 @@ int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const
     return GNN_OK;
 }
 
+// one Dense layer without activation epilogue choices hidden: Y = act(X . W + b) [then x * scale + shift]; used by the
+// training path (gnn_train.hip) for z = h . W + b and d h = d z . W^T
+int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float *X, int64_t ldx, const float *W, const float *b,
+                     int act, float *Y, int64_t ldy)
+{
+    if (n == 0) return GNN_OK;
+    constexpr int R = 8;
+    const int n_in_pad = (n_in + 3) & ~3;
+    const size_t lds = sizeof(float) * R * n_in_pad;
+    if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer input width %d too large", n_in);
+    if (act == GNN_ACT_SOFTMAX) return gnn_fail(GNN_ERR_ARG, "gnn_launch_dense: softmax is applied by the caller");
+    const int threads = std::min(256, ((n_out + 63) / 64) * 64);
+    hipLaunchKernelGGL((k_dense<R>), cdiv(n, R), threads, lds, st, n, n_in, n_in_pad, n_out, X, ldx, W, b, act, (const float *)nullptr,
+                       (const float *)nullptr, Y, ldy, (const int *)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
+int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base)
+{
+    if (n_rows == 0) return GNN_OK;
+    hipLaunchKernelGGL(k_check, cdiv(n_rows, 256), 256, 0, st, n_rows, d, s, so, thr, flag_rank_base, (const int *)nullptr, 1);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
 // Sequential forward on device buffers: X[n, dims[0]] (ldx) -> Y[n, dims.back()] (ldy); t0/t1: [n, max hidden width]
 static int launch_mlp(hipStream_t st, const gnn_mlp *m, int64_t n, const float *X, int64_t ldx, float *Y, int64_t ldy,
                       float *t0, float *t1, const int *gate, int world)

@@ -1,0 +1,562 @@
+// One training step on the device: training-mode forward through the unrolled state loop, loss, back-propagation through
+// all executed iterations (reference GNN/GNN_BaseClass.py:231-247 around GNN/GNN.py:180-199, :251-280).  The optimizer
+// step stays on the host (the weights are a few hundred KB): this file returns the loss, the iteration count, the raw
+// gradients and the BatchNormalization batch statistics of every executed body.
+//
+// Keras training semantics (not in the reference repository; restated in oracle/gnn_train_oracle.py):
+//   Dropout: y = x * mask / (1 - rate), fresh mask per call;  BatchNormalization: batch mean / biased batch variance;
+//   categorical_crossentropy(from_logits=False): p = out / sum(out), clip to [1e-7, 1 - 1e-7], -sum t log p.
+// This path is built from simple per-op kernels (correctness first; training graphs are small batches); float32 with
+// atomically accumulated weight gradients, so it is compared with the oracle to a tolerance, not bit for bit.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "gnn_common.h"
+
+namespace {
+
+inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Dropout forward: keep[i] = injected mask or own RNG; y = x * keep / (1 - rate); keep bytes are stored for the backward pass
+__global__ void k_dropout_fwd(int64_t n, const float *x, const uint8_t *mask_in, float rate, uint64_t seed, uint8_t *keep, float *y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t kp;
+    if (mask_in) kp = mask_in[i] != 0;
+    else kp = ((mix64(seed ^ mix64((uint64_t)i)) >> 40) * (1.0f / 16777216.0f)) >= rate;
+    keep[i] = kp;
+    y[i] = kp ? x[i] / (1.0f - rate) : 0.0f;
+}
+
+__global__ void k_dropout_bwd(int64_t n, const uint8_t *keep, float rate, float *d)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = keep[i] ? d[i] / (1.0f - rate) : 0.0f;
+}
+
+__global__ void k_act_fwd(int64_t n, int F, const float *z, int act, float *a)
+{
+    if (act == GNN_ACT_SOFTMAX) {
+        const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (r >= n) return;
+        const float *zr = z + r * F;
+        float *ar = a + r * F;
+        float m = zr[0];
+        for (int j = 1; j < F; ++j) m = zr[j] > m ? zr[j] : m;
+        float s = 0.0f;
+        for (int j = 0; j < F; ++j) { const float e = gnn_expf(zr[j] - m); ar[j] = e; s = s + e; }
+        for (int j = 0; j < F; ++j) ar[j] = __fdiv_rn(ar[j], s);
+    } else {
+        const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < n * F) a[i] = gnn_act(z[i], act);
+    }
+}
+
+// dz = da * act'(z) (softmax: a * (da - sum da a) per row); in place on d
+__global__ void k_act_bwd(int64_t n, int F, float *d, const float *z, const float *a, int act)
+{
+    if (act == GNN_ACT_SOFTMAX) {
+        const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (r >= n) return;
+        float s = 0.0f;
+        for (int j = 0; j < F; ++j) s += d[r * F + j] * a[r * F + j];
+        for (int j = 0; j < F; ++j) d[r * F + j] = a[r * F + j] * (d[r * F + j] - s);
+        return;
+    }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * F) return;
+    const float zz = z[i], aa = a[i];
+    float g;
+    switch (act) {
+    case GNN_ACT_RELU: g = zz > 0.0f ? 1.0f : 0.0f; break;
+    case GNN_ACT_SELU: g = zz > 0.0f ? 1.0507009873554805f : 1.0507009873554805f * 1.6732632423543772f * gnn_expf(zz); break;
+    case GNN_ACT_ELU: g = zz > 0.0f ? 1.0f : gnn_expf(zz); break;
+    case GNN_ACT_TANH: g = 1.0f - aa * aa; break;
+    case GNN_ACT_SIGMOID: g = aa * (1.0f - aa); break;
+    default: g = 1.0f; break;
+    }
+    d[i] = d[i] * g;
+}
+
+// column reductions over n rows of [n, F] matrices; one block of 256 threads = 32 columns x 8 row lanes
+// mode 0: out0[j] += sum x        mode 1: out0[j] += sum (x - aux0[j])^2        mode 2: out0[j] += sum x * y, out1[j] += sum x
+__global__ void k_colreduce(int64_t n, int F, const float *x, const float *y, const float *aux0, int mode, float *out0, float *out1,
+                            int64_t rows_per_block)
+{
+    __shared__ float s0[8][33], s1[8][33];
+    const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    float a0 = 0.0f, a1 = 0.0f;
+    if (j < F)
+        for (int64_t r = r0 + ry; r < r1; r += 8) {
+            const float v = x[r * F + j];
+            if (mode == 0) a0 += v;
+            else if (mode == 1) { const float dv = v - aux0[j]; a0 += dv * dv; }
+            else { a0 += v * y[r * F + j]; a1 += v; }
+        }
+    s0[ry][c] = a0; s1[ry][c] = a1;
+    __syncthreads();
+    if (ry == 0 && j < F) {
+        for (int t = 1; t < 8; ++t) { a0 += s0[t][c]; a1 += s1[t][c]; }
+        atomicAdd(out0 + j, a0);
+        if (mode == 2) atomicAdd(out1 + j, a1);
+    }
+}
+
+__global__ void k_scale_vec(int n, float *v, float s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = v[i] * s;
+}
+
+__global__ void k_bn_fwd(int64_t n, int F, const float *h, const float *mean, const float *sqsum, float eps, const float *gamma,
+                         const float *beta, float *xhat, float *y, float *stats /* [2][F]: batch mean, biased batch var */)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * F) return;
+    const int j = (int)(i % F);
+    const float mu = mean[j], var = sqsum[j] / (float)n;
+    const float xh = (h[i] - mu) / sqrtf(var + eps);
+    xhat[i] = xh;
+    y[i] = gamma[j] * xh + beta[j];
+    if (i < F) { stats[j] = mu; stats[F + j] = var; }
+}
+
+// d x = inv / n * (n * dxh - sum dxh - xhat * sum(dxh * xhat)), dxh = d y * gamma; sums: s_dyx = sum dy*xhat, s_dy = sum dy
+__global__ void k_bn_bwd(int64_t n, int F, float *d, const float *xhat, const float *gamma, const float *stats, float eps,
+                         const float *s_dyx, const float *s_dy)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * F) return;
+    const int j = (int)(i % F);
+    const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j], m = (float)n;
+    d[i] = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
+}
+
+// dW[i, j] += sum_r H[r, i] * DZ[r, j] over the rows of this block's chunk; 16 x 16 output tile per block
+__global__ void k_wgrad(int64_t n, int n_in, int n_out, const float *H, const float *DZ, float *dW, int64_t rows_per_block)
+{
+    __shared__ float sh[16][17], sz[16][17];
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    float acc = 0.0f;
+    for (int64_t r = r0; r < r1; r += 16) {
+        // tile rows r..r+15: thread (ti, tj) loads H[r + ti][i0 + tj] and DZ[r + ti][j0 + tj]
+        sh[ti][tj] = (r + ti < r1 && i0 + tj < n_in) ? H[(r + ti) * n_in + i0 + tj] : 0.0f;
+        sz[ti][tj] = (r + ti < r1 && j0 + tj < n_out) ? DZ[(r + ti) * n_out + j0 + tj] : 0.0f;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += sh[q][ti] * sz[q][tj];
+        __syncthreads();
+    }
+    if (i0 + ti < n_in && j0 + tj < n_out) atomicAdd(dW + (size_t)(i0 + ti) * n_out + j0 + tj, acc);
+}
+
+__global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
+{
+    const int wf = Ds + NLc;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * wf) return;
+    const int64_t q = t / wf;
+    const int c = (int)(t - q * wf);
+    const int64_t row = rows[q];
+    feats[t] = c < Ds ? state[row * Ds + c] : nodes[row * NL + (c - Ds)];
+}
+
+__global__ void k_scatter_rows(int64_t m, const int32_t *rows, const float *d_feats, int wf, int Ds, float *d_state)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * Ds) return;
+    const int64_t q = t / Ds;
+    const int c = (int)(t - q * Ds);
+    d_state[(int64_t)rows[q] * Ds + c] = d_feats[q * wf + c];
+}
+
+// d_state[r, c] = d_inp[r, c] + tmp[r, c]   (own-state columns of the concat + transposed aggregation)
+__global__ void k_combine(int64_t n, int Ds, const float *d_inp, int in_s, const float *tmp, float *d_state)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * Ds) return;
+    const int64_t r = t / Ds;
+    const int c = (int)(t - r * Ds);
+    d_state[t] = d_inp[r * in_s + c] + tmp[t];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct Buf {                      // device scratch, freed at the end of the step
+    std::vector<void *> all;
+    template <typename T>
+    int get(T **p, size_t count)
+    {
+        *p = nullptr;
+        if (hipMalloc((void **)p, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
+        all.push_back(*p);
+        return GNN_OK;
+    }
+    ~Buf() { for (void *p : all) (void)hipFree(p); }
+};
+
+struct NetCache {                 // what one training-mode forward of a Sequential leaves for the backward pass
+    std::vector<float *> hin, z, a;
+    std::vector<uint8_t *> keep;  // per dropout index 0..L (nullptr when no dropout there)
+    float *xhat = nullptr, *stats = nullptr;
+    int64_t n = 0;
+};
+
+struct Net {
+    const gnn_mlp *m = nullptr;
+    std::vector<float *> WT;      // W^T per layer
+    float *gamma = nullptr, *beta = nullptr;
+    std::vector<float> rate;      // [L + 1] dropout rate in front of Dense l (index L: in front of BatchNormalization)
+    float *grads = nullptr;       // flat: dW1, db1, ..., dgamma, dbeta
+    std::vector<size_t> g_off;
+    size_t g_total = 0;
+};
+
+int net_setup(Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host)
+{
+    net.m = m;
+    const int L = m->n_layers;
+    net.rate.assign(rates, rates + L + 1);
+    net.WT.assign(L, nullptr);
+    size_t off = 0;
+    for (int l = 0; l < L; ++l) {
+        const int ni = m->dims[l], no = m->dims[l + 1];
+        std::vector<float> W((size_t)ni * no), WT((size_t)ni * no);
+        HIPCHK(hipMemcpy(W.data(), m->W[l], W.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int i = 0; i < ni; ++i)
+            for (int j = 0; j < no; ++j) WT[(size_t)j * ni + i] = W[(size_t)i * no + j];
+        int rc = buf.get(&net.WT[l], WT.size());
+        if (rc) return rc;
+        HIPCHK(hipMemcpy(net.WT[l], WT.data(), WT.size() * sizeof(float), hipMemcpyHostToDevice));
+        net.g_off.push_back(off); off += (size_t)ni * no;
+        net.g_off.push_back(off); off += (size_t)no;
+    }
+    if (m->has_bn) {
+        const int F = m->dims.back();
+        int rc = buf.get(&net.gamma, (size_t)2 * F);
+        if (rc) return rc;
+        net.beta = net.gamma + F;
+        HIPCHK(hipMemcpy(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice));
+        net.g_off.push_back(off); off += F;
+        net.g_off.push_back(off); off += F;
+    }
+    net.g_total = off;
+    int rc = buf.get(&net.grads, off);
+    if (rc) return rc;
+    HIPCHK(hipMemset(net.grads, 0, off * sizeof(float)));
+    return GNN_OK;
+}
+
+// training-mode forward of one Sequential on n rows (x: [n, dims[0]]); *y_out: [n, dims.back()]
+int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, const uint8_t *masks, uint64_t seed, NetCache &c, float **y_out)
+{
+    const gnn_mlp *m = net.m;
+    const int L = m->n_layers;
+    c.n = n;
+    c.hin.assign(L, nullptr); c.z.assign(L, nullptr); c.a.assign(L, nullptr); c.keep.assign(L + 1, nullptr);
+    float *h = x;
+    size_t mask_off = 0;
+    int rc;
+    for (int l = 0; l <= L; ++l) {
+        const int width = m->dims[l];
+        if (net.rate[l] > 0.0f) {
+            float *hd = nullptr;
+            if ((rc = buf.get(&hd, (size_t)n * width)) || (rc = buf.get(&c.keep[l], (size_t)n * width))) return rc;
+            if (n > 0) {
+                hipLaunchKernelGGL(k_dropout_fwd, cdiv(n * width, 256), 256, 0, st, n * width, h, masks ? masks + mask_off : nullptr, net.rate[l],
+                                   seed + 0x9E37ull * (uint64_t)(l + 1), c.keep[l], hd);
+                HIPCHK(hipGetLastError());
+            }
+            mask_off += (size_t)n * width;
+            h = hd;
+        }
+        if (l == L) break;
+        const int no = m->dims[l + 1];
+        c.hin[l] = h;
+        if ((rc = buf.get(&c.z[l], (size_t)n * no)) || (rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
+        if ((rc = gnn_launch_dense(st, n, width, no, h, width, m->W[l], m->b[l], GNN_ACT_LINEAR, c.z[l], no))) return rc;
+        if (n > 0) {
+            const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;
+            hipLaunchKernelGGL(k_act_fwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, c.z[l], m->acts[l], c.a[l]);
+            HIPCHK(hipGetLastError());
+        }
+        h = c.a[l];
+    }
+    if (m->has_bn) {
+        const int F = m->dims.back();
+        float *sums = nullptr, *y = nullptr;
+        if ((rc = buf.get(&sums, (size_t)2 * F)) || (rc = buf.get(&c.xhat, (size_t)n * F)) || (rc = buf.get(&c.stats, (size_t)2 * F)) ||
+            (rc = buf.get(&y, (size_t)n * F))) return rc;
+        HIPCHK(hipMemsetAsync(sums, 0, sizeof(float) * 2 * F, st));
+        HIPCHK(hipMemsetAsync(c.stats, 0, sizeof(float) * 2 * F, st));
+        if (n > 0) {
+            const int64_t rpb = 1024;
+            dim3 grid(cdiv(F, 32), cdiv(n, rpb));
+            hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, h, (const float *)nullptr, (const float *)nullptr, 0, sums, (float *)nullptr, rpb);
+            hipLaunchKernelGGL(k_scale_vec, cdiv(F, 64), 64, 0, st, F, sums, 1.0f / (float)n);                       // sums -> batch mean
+            hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, h, (const float *)nullptr, sums, 1, sums + F, (float *)nullptr, rpb);
+            hipLaunchKernelGGL(k_bn_fwd, cdiv(n * F, 256), 256, 0, st, n, F, h, sums, sums + F, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
+            HIPCHK(hipGetLastError());
+        }
+        h = y;
+    }
+    *y_out = h;
+    return GNN_OK;
+}
+
+// back-propagation through one Sequential: d is d loss / d y on entry ([n, dims.back()], overwritten); on return *dx_out is
+// d loss / d x ([n, dims[0]]); weight gradients are ADDED into net.grads
+int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d, float **dx_out)
+{
+    const gnn_mlp *m = net.m;
+    const int L = m->n_layers;
+    const int64_t n = c.n;
+    int rc;
+    const int64_t rpb = 1024;
+    if (m->has_bn && n > 0) {
+        const int F = m->dims.back();
+        float *dgamma = net.grads + net.g_off[2 * L], *dbeta = net.grads + net.g_off[2 * L + 1];
+        float *loc = nullptr;                      // this call's own column sums (the grads accumulate over iterations)
+        if ((rc = buf.get(&loc, (size_t)2 * F))) return rc;
+        HIPCHK(hipMemsetAsync(loc, 0, sizeof(float) * 2 * F, st));
+        dim3 grid(cdiv(F, 32), cdiv(n, rpb));
+        hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, d, c.xhat, (const float *)nullptr, 2, loc, loc + F, rpb);
+        hipLaunchKernelGGL(k_bn_bwd, cdiv(n * F, 256), 256, 0, st, n, F, d, c.xhat, net.gamma, c.stats, m->eps, loc, loc + F);
+        // dgamma += loc[0:F], dbeta += loc[F:2F]
+        hipLaunchKernelGGL(k_colreduce, dim3(cdiv(F, 32), 1), 256, 0, st, 1, F, loc, (const float *)nullptr, (const float *)nullptr, 0, dgamma, (float *)nullptr, (int64_t)1);
+        hipLaunchKernelGGL(k_colreduce, dim3(cdiv(F, 32), 1), 256, 0, st, 1, F, loc + F, (const float *)nullptr, (const float *)nullptr, 0, dbeta, (float *)nullptr, (int64_t)1);
+        HIPCHK(hipGetLastError());
+    }
+    if (net.rate[L] > 0.0f && n > 0) {
+        const int F = m->dims.back();
+        hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * F, 256), 256, 0, st, n * F, c.keep[L], net.rate[L], d);
+        HIPCHK(hipGetLastError());
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const int ni = m->dims[l], no = m->dims[l + 1];
+        float *dprev = nullptr;
+        if ((rc = buf.get(&dprev, (size_t)n * ni))) return rc;
+        if (n > 0) {
+            const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;
+            hipLaunchKernelGGL(k_act_bwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, d, c.z[l], c.a[l], m->acts[l]);
+            dim3 gw(cdiv(ni, 16), cdiv(no, 16), cdiv(n, rpb));
+            hipLaunchKernelGGL(k_wgrad, gw, 256, 0, st, n, ni, no, c.hin[l], d, net.grads + net.g_off[2 * l], rpb);
+            dim3 gb(cdiv(no, 32), cdiv(n, rpb));
+            hipLaunchKernelGGL(k_colreduce, gb, 256, 0, st, n, no, d, (const float *)nullptr, (const float *)nullptr, 0, net.grads + net.g_off[2 * l + 1], (float *)nullptr, rpb);
+            HIPCHK(hipGetLastError());
+        }
+        // d h_in = d z . W^T  (bias-free: reuse the zero tail of the gradient buffer? no: a dedicated zero vector)
+        float *zero = nullptr;
+        if ((rc = buf.get(&zero, (size_t)ni))) return rc;
+        HIPCHK(hipMemsetAsync(zero, 0, sizeof(float) * ni, st));
+        if ((rc = gnn_launch_dense(st, n, no, ni, d, no, net.WT[l], zero, GNN_ACT_LINEAR, dprev, ni))) return rc;
+        if (net.rate[l] > 0.0f && n > 0) {
+            hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * ni, 256), 256, 0, st, n * ni, c.keep[l], net.rate[l], dprev);
+            HIPCHK(hipGetLastError());
+        }
+        d = dprev;
+    }
+    *dx_out = d;
+    return GNN_OK;
+}
+
+// host side of the loss (rows are few): sum_i w_i L(t_i, o_i) and d / d o
+void loss_host(int kind, int64_t n, int T, const float *t, const float *o, const float *w, double *loss, std::vector<float> &d_o)
+{
+    d_o.assign((size_t)n * T, 0.0f);
+    double total = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *ti = t + i * T, *oi = o + i * T;
+        if (kind == 0) {                           // categorical_crossentropy, from_logits=False
+            double s = 0.0;
+            for (int j = 0; j < T; ++j) s += oi[j];
+            std::vector<double> p(T), g(T);
+            double li = 0.0, gp = 0.0;
+            for (int j = 0; j < T; ++j) {
+                p[j] = oi[j] / s;
+                const bool in = p[j] >= 1e-7 && p[j] <= 1.0 - 1e-7;
+                const double pc = std::min(std::max(p[j], 1e-7), 1.0 - 1e-7);
+                li -= ti[j] * log(pc);
+                g[j] = in ? -ti[j] / pc : 0.0;
+                gp += g[j] * p[j];
+            }
+            for (int j = 0; j < T; ++j) d_o[i * T + j] = (float)(w[i] * (g[j] - gp) / s);
+            total += w[i] * li;
+        } else {                                   // mean_squared_error
+            double li = 0.0;
+            for (int j = 0; j < T; ++j) { const double e = (double)oi[j] - ti[j]; li += e * e; d_o[i * T + j] = (float)(w[i] * 2.0 * e / T); }
+            total += w[i] * li / T;
+        }
+    }
+    *loss = total;
+}
+
+}   // namespace
+
+extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
+                                   const float *targets, const float *sample_weights, int64_t n_targets, int loss_kind,
+                                   int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w,
+                                   const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
+                                   const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
+                                   float *loss_out, float *k_out, float *grads_state, float *grads_output,
+                                   float *bn_batch_state, float *bn_batch_output)
+{
+    ARGCHK(l && src_indptr && targets && sample_weights && dropout_state && dropout_output && loss_out && k_out && grads_state && grads_output,
+           "bad arguments");
+    ARGCHK(l->world == 1 && !l->edge_mode && !l->edge_expected, "training is single-GPU, node/graph-based only");
+    ARGCHK(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error");
+    ARGCHK(!l->st->has_bn || bn_state, "net_state ends with BatchNormalization: gamma|beta required");
+    ARGCHK(!l->ou->has_bn || bn_output, "net_output ends with BatchNormalization: gamma|beta required");
+    if (!l->have_state0 && l->D) return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
+    gnn_graph *g = l->g;
+    const int64_t N = g->n_rows, M = g->n_masked, E = g->E;
+    const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->wf;
+    ARGCHK(n_targets == (n_graphs > 0 ? n_graphs : M), "%lld target rows but %lld outputs", (long long)n_targets, (long long)(n_graphs > 0 ? n_graphs : M));
+    HIPCHK(hipSetDevice(l->device));
+    hipStream_t st = l->stream;
+    Buf buf;
+    int rc;
+    Net ns, no_;
+    if ((rc = net_setup(buf, ns, l->st, dropout_state, bn_state)) || (rc = net_setup(buf, no_, l->ou, dropout_output, bn_output))) return rc;
+    // Adjacency by source for the transposed aggregation of the backward pass
+    int32_t *d_sip = nullptr, *d_sdst = nullptr;
+    float *d_sw = nullptr;
+    if ((rc = buf.get(&d_sip, (size_t)N + 1)) || (rc = buf.get(&d_sdst, (size_t)E)) || (rc = buf.get(&d_sw, (size_t)E))) return rc;
+    ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E, "bad by-source CSR");
+    HIPCHK(hipMemcpy(d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
+    if (E) { HIPCHK(hipMemcpy(d_sdst, src_dst, sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_sw, src_w, sizeof(float) * E, hipMemcpyHostToDevice)); }
+
+    // template of the concat with the loop-invariant columns filled in (GNN.py:259, :263)
+    float *tmpl = nullptr;
+    if ((rc = buf.get(&tmpl, (size_t)N * in_s))) return rc;
+    HIPCHK(hipMemsetAsync(tmpl, 0, sizeof(float) * (size_t)N * in_s, st));
+    const int c_nodes = Ds, c_aggs = Ds + NLc, c_aggn = c_aggs + Ds, c_agga = c_aggn + NLc;
+    if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
+    if (l->D) {
+        if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, tmpl + c_aggn, in_s, nullptr, 1))) return rc;
+        if (N) HIPCHK(hipMemcpy2DAsync(tmpl + c_nodes, sizeof(float) * in_s, g->nodes, sizeof(float) * g->NL, sizeof(float) * g->NL, (size_t)N, hipMemcpyDeviceToDevice, st));
+    }
+    // state, condition flags
+    float *state = nullptr, *state_old = nullptr;
+    int *flag = nullptr;
+    if ((rc = buf.get(&state, (size_t)N * Ds)) || (rc = buf.get(&state_old, (size_t)N * Ds)) || (rc = buf.get(&flag, (size_t)GNN_FLAG_WORDS))) return rc;
+    if (N) HIPCHK(hipMemcpyAsync(state, l->D ? l->state_init : g->nodes, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+    std::vector<int> hflag(GNN_FLAG_WORDS);
+    auto not_converged = [&](const float *s, const float *so, bool *go) -> int {
+        HIPCHK(hipMemsetAsync(flag, 0, sizeof(int) * GNN_FLAG_WORDS, st));
+        int r = gnn_launch_check(st, N, Ds, s, so, l->thr, flag);
+        if (r) return r;
+        HIPCHK(hipMemcpyAsync(hflag.data(), flag, sizeof(int) * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int any = 0;
+        for (int i = 0; i < GNN_FLAG_WORDS; i += GNN_FLAG_STRIDE) any |= hflag[i];
+        *go = any != 0;
+        return GNN_OK;
+    };
+    // masks of one iteration of net_state: sum over the dropout positions of N * width bytes
+    size_t mask_iter_bytes = 0;
+    for (int i = 0; i <= l->st->n_layers; ++i) if (dropout_state[i] > 0.0f) mask_iter_bytes += (size_t)N * l->st->dims[i];
+    size_t mask_out_bytes = 0;
+    for (int i = 0; i <= l->ou->n_layers; ++i) if (dropout_output[i] > 0.0f) mask_out_bytes += (size_t)M * l->ou->dims[i];
+    uint8_t *d_masks_s = nullptr, *d_masks_o = nullptr;
+    if (masks_state && mask_iter_bytes) {
+        if ((rc = buf.get(&d_masks_s, mask_iter_bytes * (size_t)l->max_iter))) return rc;
+        HIPCHK(hipMemcpy(d_masks_s, masks_state, mask_iter_bytes * (size_t)l->max_iter, hipMemcpyHostToDevice));
+    }
+    if (masks_output && mask_out_bytes) {
+        if ((rc = buf.get(&d_masks_o, mask_out_bytes))) return rc;
+        HIPCHK(hipMemcpy(d_masks_o, masks_output, mask_out_bytes, hipMemcpyHostToDevice));
+    }
+
+    // ---- forward: while condition: state <- net_state(concat), training mode (GNN.py:271 with training=True) -----------
+    std::vector<NetCache> caches;
+    bool go = false;
+    if ((rc = not_converged(state, nullptr, &go))) return rc;
+    int k = 0;
+    while (go && k < l->max_iter) {
+        float *inp = nullptr, *y = nullptr;
+        if ((rc = buf.get(&inp, (size_t)N * in_s))) return rc;
+        HIPCHK(hipMemcpyAsync(inp, tmpl, sizeof(float) * (size_t)N * in_s, hipMemcpyDeviceToDevice, st));
+        if (N) HIPCHK(hipMemcpy2DAsync(inp, sizeof(float) * in_s, state, sizeof(float) * Ds, sizeof(float) * Ds, (size_t)N, hipMemcpyDeviceToDevice, st));
+        if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, state, Ds, Ds, inp + c_aggs, in_s, nullptr, 1))) return rc;
+        caches.emplace_back();
+        if ((rc = net_forward(st, buf, ns, N, inp, d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)k : nullptr, seed + 7919ull * (uint64_t)(k + 1),
+                              caches.back(), &y))) return rc;
+        std::swap(state, state_old);
+        if (N) HIPCHK(hipMemcpyAsync(state, y, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+        ++k;
+        if ((rc = not_converged(state, state_old, &go))) return rc;
+    }
+    // ---- net_output on the masked rows, loss -------------------------------------------------------------------------------
+    float *feats = nullptr, *out_nodes = nullptr;
+    if ((rc = buf.get(&feats, (size_t)M * wf))) return rc;
+    if (M) {
+        hipLaunchKernelGGL(k_gather_feats, cdiv(M * wf, 256), 256, 0, st, M, g->sh->masked_rows, state, Ds, g->nodes, g->NL, NLc, feats);
+        HIPCHK(hipGetLastError());
+    }
+    NetCache co;
+    if ((rc = net_forward(st, buf, no_, M, feats, d_masks_o, seed + 104729ull, co, &out_nodes))) return rc;
+    std::vector<float> h_out((size_t)M * T), h_dnodes((size_t)M * T, 0.0f), d_o;
+    if (M) HIPCHK(hipMemcpyAsync(h_out.data(), out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double loss = 0.0;
+    if (n_graphs > 0) {                            // GNNgraphBased: out = NodeGraph^T . out_nodes (GNN.py:331-332)
+        std::vector<float> og((size_t)n_graphs * T, 0.0f);
+        for (int gi = 0; gi < n_graphs; ++gi)
+            for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e)
+                for (int t = 0; t < T; ++t) og[(size_t)gi * T + t] += ng_w[e] * h_out[(size_t)ng_node[e] * T + t];
+        loss_host(loss_kind, n_graphs, T, targets, og.data(), sample_weights, &loss, d_o);
+        for (int gi = 0; gi < n_graphs; ++gi)
+            for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e)
+                for (int t = 0; t < T; ++t) h_dnodes[(size_t)ng_node[e] * T + t] += ng_w[e] * d_o[(size_t)gi * T + t];
+    } else {
+        loss_host(loss_kind, M, T, targets, h_out.data(), sample_weights, &loss, h_dnodes);
+    }
+    // ---- backward ---------------------------------------------------------------------------------------------------------
+    float *d_out = nullptr, *d_feats = nullptr, *d_state = nullptr, *tmp = nullptr;
+    if ((rc = buf.get(&d_out, (size_t)M * T)) || (rc = buf.get(&d_state, (size_t)N * Ds)) || (rc = buf.get(&tmp, (size_t)N * Ds))) return rc;
+    if (M) HIPCHK(hipMemcpyAsync(d_out, h_dnodes.data(), sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, st));
+    if ((rc = net_backward(st, buf, no_, co, d_out, &d_feats))) return rc;
+    HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)N * Ds, st));
+    if (M) {
+        hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, d_state);
+        HIPCHK(hipGetLastError());
+    }
+    for (int it = k - 1; it >= 0; --it) {
+        float *d_inp = nullptr, *dy = nullptr;
+        if ((rc = buf.get(&dy, (size_t)N * Ds))) return rc;                       // net_backward overwrites its input
+        if (N) HIPCHK(hipMemcpyAsync(dy, d_state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+        if ((rc = net_backward(st, buf, ns, caches[it], dy, &d_inp))) return rc;
+        // aggregated_states = Adjacency^T . state  =>  d state[src] = d inp[src, :Ds] + sum over arcs (src -> dst) of w * d agg[dst]
+        if ((rc = gnn_launch_spmm(st, N, d_sip, d_sdst, d_sw, d_inp + c_aggs, Ds, in_s, tmp, Ds, nullptr, 1))) return rc;
+        if (N) {
+            hipLaunchKernelGGL(k_combine, cdiv(N * Ds, 256), 256, 0, st, N, Ds, d_inp, in_s, tmp, d_state);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    HIPCHK(hipMemcpyAsync(grads_state, ns.grads, sizeof(float) * ns.g_total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(grads_output, no_.grads, sizeof(float) * no_.g_total, hipMemcpyDeviceToHost, st));
+    if (bn_batch_state && l->st->has_bn)
+        for (int it = 0; it < k; ++it)
+            HIPCHK(hipMemcpyAsync(bn_batch_state + (size_t)it * 2 * Ds, caches[it].stats, sizeof(float) * 2 * Ds, hipMemcpyDeviceToHost, st));
+    if (bn_batch_output && l->ou->has_bn && M) HIPCHK(hipMemcpyAsync(bn_batch_output, co.stats, sizeof(float) * 2 * T, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *loss_out = (float)loss;
+    *k_out = (float)k;
+    return GNN_OK;
+}

@@ -112,6 +112,30 @@ int gnn_loop_readout(const gnn_loop *l, int n_graphs, const int32_t *ng_indptr, 
  * lists; SURVEY.md 8a quirk 6, reproduced as is).  arc_mask = set_mask & output_mask over arcs.  net_output must take
  * 2 (NL [D>0] + Ds) + AL inputs (GNN/MLP.py:109).  Single GPU only. */
 int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, const float *arc_labels, const uint8_t *arc_mask);
+/* One training step without the optimizer (reference GNN/GNN_BaseClass.py:231-247: GradientTape around
+ * evaluate_single_graph(training=True), GNN/GNN.py:180-199): training-mode forward through the unrolled loop (Dropout masks,
+ * BatchNormalization batch statistics), loss = sum_i w_i L(t_i, out_i), back-propagation through every executed body.
+ *   src_*            Adjacency in CSR form BY SOURCE (rows = source node, inner = destination ascending): the transposed
+ *                    aggregation of the backward pass
+ *   targets, sample_weights, n_targets   rows = masked nodes (node-based) or graphs (graph-based); loss_kind 0 =
+ *                    categorical_crossentropy(from_logits=False), 1 = mean_squared_error
+ *   n_graphs, ng_*   NodeGraph^T in CSR form (as gnn_loop_readout) for GNNgraphBased, n_graphs = 0 otherwise
+ *   dropout_state / dropout_output   [n_layers + 1] Dropout rate in front of Dense l (0 = none; last entry: in front of
+ *                    BatchNormalization), i.e. GNN/MLP.py:54-55 after its position shift
+ *   masks_*          injected keep-masks (uint8, 1 = keep): for net_state max_iter blocks, each the concatenation over the
+ *                    dropout positions of [N, width]; for net_output one such block over the masked rows; NULL = engine RNG(seed)
+ *   bn_state / bn_output   [gamma | beta] of the trailing BatchNormalization (NULL without one)
+ * Outputs: *loss_out, *k_out (executed bodies), grads_* flat in get_weights() order of the TRAINABLE arrays
+ * [dW1, db1, ..., dgamma, dbeta] (raw sums over the iterations: the division by k of :241 is the caller's), bn_batch_state
+ * [k][2][Ds] and bn_batch_output [2][T] = batch mean / biased batch variance of every BatchNormalization call (the caller
+ * applies the moving-average updates).  Single GPU, node/graph-based. */
+int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
+                        const float *targets, const float *sample_weights, int64_t n_targets, int loss_kind,
+                        int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w,
+                        const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
+                        const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
+                        float *loss_out, float *k_out, float *grads_state, float *grads_output,
+                        float *bn_batch_state, float *bn_batch_output);
 /* selects the implementation: 0 = unfused reference kernels (one kernel per TF op), 1 = fused gather+MLP kernel
  * when the shapes allow it (default), falling back to 0 otherwise.  *used (may be NULL) reports the choice. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);

@@ -1,0 +1,85 @@
+"""One training step on the device (gnn_loop_train_step) against the float64 training oracle: loss, iteration count,
+gradients of every trainable array, BatchNormalization batch statistics.  Tolerance-based (float32, atomically accumulated
+weight gradients; BatchNormalization right after a softmax is ill-conditioned): 1e-3 relative to the largest entry of each gradient array."""
+import numpy as np
+import pytest
+
+from oracle import gnn_oracle as orc
+from oracle import gnn_train_oracle as tro
+from util import make_mlp, random_arcs
+
+pytestmark = pytest.mark.gpu
+
+
+def _by_source_csr(g, n):
+    indptr, src, w = g['adjT']
+    dst = np.repeat(np.arange(n), np.diff(indptr))
+    order = np.lexsort((dst, src))
+    sip = np.zeros(n + 1, np.int32)
+    np.cumsum(np.bincount(src, minlength=n), out=sip[1:])
+    return sip, dst[order].astype(np.int32), np.asarray(w, np.float32)[order]
+
+
+@pytest.mark.parametrize('d,graph_based,act,loss', [(8, False, 'tanh', 'categorical_crossentropy'), (0, False, 'selu', 'categorical_crossentropy'),
+                                                      (5, True, 'sigmoid', 'mean_squared_error'), (0, True, 'relu', 'categorical_crossentropy')])
+def test_train_step_matches_oracle(d, graph_based, act, loss):
+    from GNN import _engine as e
+    rng = np.random.default_rng(100 + d)
+    n, nl, al, max_it = 500, 3, 2, 6
+    arcs = random_arcs(rng, n, 1500, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    ng = None
+    if graph_based:
+        ng = np.zeros((n, 3), np.float32); ng[:200, 0] = 1 / 200; ng[200:350, 1] = 1 / 150; ng[350:, 2] = 1 / 150
+    g = orc.make_graph_dict(arcs, nodes, 'average', NodeGraph=ng)
+    if not graph_based:
+        g['set_mask'] = rng.random(n) < 0.8
+    ds, nlc = (d if d else nl), (nl if d else 0)
+    st = make_mlp(rng, al + 2 * (ds + nlc), [16, ds], act, gain=0.8, bn_random=True)
+    ou = make_mlp(rng, ds + nlc, [9, 2], act, out_activation='softmax', bn_random=True)
+    st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1, 1: 0.3}
+    mask = g['set_mask'] & g['output_mask']
+    m = int(mask.sum())
+    in_s = st['weights'][0].shape[0]
+    masks_s = [{0: (rng.random((n, in_s)) > 0.2)} for _ in range(max_it)]
+    masks_o = {0: rng.random((m, ds + nlc)) > 0.1, 1: rng.random((m, 9)) > 0.3}
+    n_t = 3 if graph_based else m
+    targets = np.eye(2)[rng.integers(0, 2, n_t)].astype(np.float32)
+    weights = rng.uniform(0.5, 1.5, n_t).astype(np.float32)
+    s0 = (0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None
+    ref = tro.train_step(g, st, ou, d, max_it, 0.05, s0, masks_s, masks_o, targets, weights, loss=loss, mean=False, graph_based=graph_based)
+
+    graph = e.Graph(n, g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], np.asarray(g['arcs'])[:, 2:][g['arcT'][1]], nodes, mask)
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    loop = e.Loop(graph, mst, mou, d, max_it, 0.05)
+    if d:
+        loop.set_state0(s0)
+    ms = np.concatenate([masks_s[k][0].astype(np.uint8).ravel() for k in range(max_it)])
+    mo = np.concatenate([masks_o[0].astype(np.uint8).ravel(), masks_o[1].astype(np.uint8).ravel()])
+    ng_csr = None
+    if graph_based:
+        cols, rows = np.nonzero(ng.T)
+        ip = np.zeros(4, np.int32); np.cumsum(np.bincount(cols, minlength=3), out=ip[1:])
+        ng_csr = (ip, rows.astype(np.int32), ng[rows, cols])
+    res = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0 if loss == 'categorical_crossentropy' else 1, ng_csr,
+                          dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], masks_state=ms, masks_output=mo,
+                          bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]), max_iter=max_it)
+    assert res['k'] == ref['k'] and 1 <= res['k'] <= max_it
+    assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    for got, want in list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output'])):
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want))), (got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)))
+    k = int(res['k'])
+    # batch statistics -> the moving averages the caller derives from them
+    mov = [np.asarray(v, np.float64).copy() for v in st['weights'][-2:]]
+    for it in range(k):
+        mov[0] = mov[0] * 0.99 + res['bn_batch_state'][it, 0] * 0.01
+        mov[1] = mov[1] * 0.99 + res['bn_batch_state'][it, 1] * 0.01
+    np.testing.assert_allclose(mov[0], ref['moving_state'][0], atol=1e-5)
+    np.testing.assert_allclose(mov[1], ref['moving_state'][1], atol=1e-5)
+    np.testing.assert_allclose(np.asarray(ou['weights'][-2], np.float64) * 0.99 + res['bn_batch_output'][0] * 0.01, ref['moving_output'][0], atol=1e-5)
+    # engine RNG masks: same call without injected masks must run and give finite numbers with about the right keep rate
+    res2 = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0 if loss == 'categorical_crossentropy' else 1, ng_csr,
+                           dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], seed=5,
+                           bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]), max_iter=max_it)
+    assert np.isfinite(res2['loss']) and all(np.isfinite(a).all() for a in res2['grads_state'] + res2['grads_output'])
