@@ -112,6 +112,47 @@ class GNNnodeBased(BaseClass):
             loop.set_state0(state0, self.seed)
         return loop.run(False), loop
 
+    # ---- training -------------------------------------------------------------------------------------------------------
+    _graph_based = False
+
+    def training_step(self, g: GraphTensor, mean: bool, *, state0=None, masks_state=None, masks_output=None) -> dict:
+        """One batch: device gradients (gnn_loop_train_step), net_state gradients divided by the iteration count when
+        ``mean`` (reference GNN_BaseClass.py:241), optimizer update, BatchNormalization moving statistics.  Returns the raw
+        result of the device step (loss, k, gradients) for inspection."""
+        from GNN import losses
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        for layer in self.get_dense_layers():
+            if layer.kernel_regularizer is not None or layer.bias_regularizer is not None:
+                raise NotImplementedError('kernel/bias regularizers are not implemented for training on the MI355X engine')
+        if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
+            raise TypeError('train() needs an optimizer with apply_gradients, e.g. GNN.optimizers.Adam()')
+        kind = losses.device_loss_kind(self.loss_function, self.loss_args)
+        if self._graph_based and not g.loop_mask().all():
+            raise ValueError('graph-based GNN needs set_mask and output_mask all True')
+        loop = self._device_loop(g.device_graph(self.device))
+        if self.state_vect_dim > 0:
+            self.seed += 1
+            loop.set_state0(state0, self.seed)
+        targets = self.get_filtered_tensor(g, g.targets)
+        weights = self.get_filtered_tensor(g, g.sample_weights)
+        if not hasattr(g, '_by_source'):
+            g._by_source = g.adjacency_by_source()
+        self._train_calls = getattr(self, '_train_calls', 0) + 1
+        res = loop.train_step(self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device), g._by_source, targets, weights,
+                              kind, g.nodegraph_csr() if self._graph_based else None, dropout_state=self.net_state.dropout_rates(),
+                              dropout_output=self.net_output.dropout_rates(), masks_state=masks_state, masks_output=masks_output,
+                              seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),
+                              bn_output=self.net_output.bn_gamma_beta(), max_iter=self.max_iteration)
+        k = res['k']
+        gs = [a / k for a in res['grads_state']] if (mean and k) else res['grads_state']
+        ws, wo = self.net_state.trainable_variables, self.net_output.trainable_variables
+        new = self.optimizer.apply_gradients(zip(gs + res['grads_output'], ws + wo))
+        self.net_state.set_trainable(new[:len(ws)])
+        self.net_output.set_trainable(new[len(ws):])
+        self.net_state.update_moving_statistics(res['bn_batch_state'])
+        if loop.n_masked: self.net_output.update_moving_statistics(res['bn_batch_output'])
+        return res
+
     def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
         """(k, state [N, Ds], out [M, T]) with k a float as in the reference (GNN.py:267, :280)."""
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
@@ -138,9 +179,14 @@ class GNNedgeBased(GNNnodeBased):
         k = loop.run(False)
         return k, loop.state(), loop.output()
 
+    def training_step(self, g, mean: bool, **_):
+        raise NotImplementedError('GNNedgeBased.train(): the backward pass of the per-arc readout is not implemented on the MI355X engine yet')
+
 
 class GNNgraphBased(GNNnodeBased):
     """GNN for graph-based problems: node-based Loop followed by the NodeGraph readout (reference GNN.py:318-333)."""
+
+    _graph_based = True
 
     @staticmethod
     def get_filtered_tensor(g: GraphTensor, inp):

@@ -4,8 +4,9 @@
 Everything here is host-side orchestration around ``Loop`` (which runs on the MI355X).  Differences from the reference,
 all deliberate:
   * the constructor does NOT delete ``path_writer`` (reference GNN_BaseClass.py:58 rmtree's it); call ``clear_writer()``;
-  * ``train`` needs back-propagation through the unrolled loop, which the device engine does not provide yet: it raises
-    ``NotImplementedError`` instead of silently training on a CPU fallback.
+  * ``train`` computes its gradients on the device (``gnn_loop_train_step``: training-mode forward, loss, back-propagation
+    through the unrolled loop) and applies the optimizer on the host; TensorBoard summaries are not written.  Model types
+    without a device backward pass (edge-based GNN, LGNN) raise ``NotImplementedError`` rather than fall back to a CPU.
 """
 from __future__ import annotations
 
@@ -97,13 +98,60 @@ class BaseClass(ABC):
             mt.ROC(targets, y_score, rocdir, micro_and_macro, pos_label=pos_label)
         return metrics
 
+    def training_step(self, g: GraphTensor, mean: bool) -> None:
+        """Gradients of one batch and the optimizer update (reference GNN_BaseClass.py:231-247); provided by GNN / LGNN."""
+        raise NotImplementedError(f'{type(self).__name__}.train(): back-propagation for this model type is not implemented '
+                                  f'on the MI355X engine yet')
+
     def train(self, gTr, epochs: int, gVa=None, update_freq: int = 10, max_fails: int = 10, observed_metric='Loss', policy='min',
               *, mean: bool = True, verbose: int = 3) -> None:
-        """Same signature as reference GNN_BaseClass.py:192-195."""
+        """Learning procedure with the reference's signature and bookkeeping (GNN_BaseClass.py:192-335): one training_step per
+        batch and epoch; every ``update_freq`` epochs the training (and validation) sets are evaluated into ``self.history``;
+        early stopping on ``observed_metric`` of gVa after ``max_fails`` evaluations without improvement, restoring the best
+        weights.  TensorBoard summaries of the reference are not written."""
         if verbose not in range(4): raise ValueError('param <verbose> not in [0,1,2,3]')
-        self.checktype(gTr), self.checktype(gVa)
-        raise NotImplementedError('train(): back-propagation through the unrolled state loop (reference GNN_BaseClass.py:231-247) '
-                                  'is not implemented on the MI355X engine yet; forward Loop/evaluate/test are')
+        gTr = self.checktype(gTr)
+        gVa = self.checktype(gVa)
+        if not self.history:
+            keys = ['Epoch'] + [i + j for i in ['It', 'Loss'] + list(self.extra_metrics) for j in ([' Tr', ' Va'] if gVa else [' Tr'])]
+            if gVa: keys += ['Fail', f'Best {observed_metric} Va']
+            self.history.update({i: list() for i in keys})
+        best_key = f'Best {observed_metric} Va'
+        if gVa:
+            assert policy in ['min', 'max']
+            better = np.less if policy == 'min' else np.greater
+            best = self.history[best_key][-1] if self.history[best_key] else (float(1e30) if policy == 'min' else float(-1e30))
+            fails, best_ws, best_wo = 0, *self.get_weights()
+        first = self.history['Epoch'][-1] + 1 if self.history['Epoch'] else 0
+        last = first + epochs
+        stopped = False
+        for e in range(first, last):
+            for i, batch in enumerate(gTr):
+                self.training_step(batch, mean=mean)
+                if verbose > 2: print(f' > Epoch {e:4d}/{last} \t\t> Batch {i + 1:4d}/{len(gTr)}', end='\r')
+            if e % update_freq == 0:
+                metrics_tr, *_ = self.evaluate(gTr)
+                self.history['Epoch'].append(e)
+                for key, val in metrics_tr.items(): self.history[f'{key} Tr'].append(val)
+                if gVa:
+                    metrics_va, *_ = self.evaluate(gVa)
+                    value = metrics_va[observed_metric]
+                    if better(value, best):
+                        best, fails = value, 0
+                        best_ws, best_wo = self.get_weights()
+                    else:
+                        fails += 1
+                    self.history[best_key].append(best)
+                    self.history['Fail'].append(fails)
+                    for key, val in metrics_va.items(): self.history[f'{key} Va'].append(val)
+                    if fails >= max_fails:
+                        if verbose in [1, 3]: self.printHistory()
+                        print('\r Validation Stop')
+                        stopped = True
+                        break
+                if verbose in [1, 3]: self.printHistory()
+        if not stopped: print('\r End of Epochs Stop')
+        if gVa: self.set_weights(best_ws, best_wo)
 
     def LKO(self, batches, epochs: int = 500, training_mode=None, update_freq: int = 10, max_fails: int = 10,
             observed_metric: str = 'Loss', policy='min', mean: bool = True, verbose: int = 3) -> dict:

@@ -154,4 +154,16 @@ class LGNN(BaseClass):
         assert training_mode in ['parallel', 'serial', 'residual']
         if (self.training_mode is not None) and (self.training_mode != training_mode): raise ValueError
         self.training_mode = training_mode
-        super().train(gTr, epochs, gVa, update_freq, max_fails, observed_metric, policy, mean=mean, verbose=verbose)
+        if training_mode == 'serial':
+            # layers are trained one after the other on graphs relabelled by the previous layer (reference LGNN.py:325-340)
+            gTr1, gVa1 = self.checktype(gTr), self.checktype(gVa)
+            gTr0, gVa0 = gTr1, gVa1
+            for idx, gnn in enumerate(self.gnns):
+                if verbose in [1, 3]: print(f'\n\n------------------- GNN{idx} -------------------\n')
+                gnn.train(gTr1, epochs, gVa1, update_freq, max_fails, observed_metric, policy, mean=mean, verbose=verbose)
+                node_loop = lambda g: GNNnodeBased.Loop(gnn, g)
+                gTr1 = [self.update_graph(g, *node_loop(gt)[1:]) for g, gt in zip(gTr0, gTr1)]
+                if gVa0: gVa1 = [self.update_graph(g, *node_loop(gt)[1:]) for g, gt in zip(gVa0, gVa1)]
+            return
+        raise NotImplementedError("LGNN.train(training_mode='parallel' | 'residual'): joint back-propagation through the stack is "
+                                  "not implemented on the MI355X engine yet (training_mode='serial' is)")

@@ -166,6 +166,47 @@ class Sequential:
             out += [self.layers[-1].gamma, self.layers[-1].beta]
         return out
 
+    # ---- training-side views (used by BaseClass.train through gnn_loop_train_step) ------------------------------------
+    def dropout_rates(self):
+        """[n_dense + 1] Dropout rate in front of Dense l (last entry: in front of BatchNormalization); 0 = none."""
+        rates, idx = [0.0] * (len(self.dense_layers) + 1), 0
+        for layer in self.layers:
+            if isinstance(layer, Dense):
+                idx += 1
+            elif isinstance(layer, AlphaDropout):
+                raise NotImplementedError('AlphaDropout in training mode is not implemented on the MI355X engine')
+            elif isinstance(layer, Dropout):
+                rates[idx] = float(layer.rate)
+        return rates
+
+    def bn_gamma_beta(self):
+        if not self.batch_normalization:
+            return None
+        return np.concatenate([self.layers[-1].gamma, self.layers[-1].beta]).astype(np.float32)
+
+    def set_trainable(self, arrays):
+        """Write back [W1, b1, ..., gamma, beta] (the order of ``trainable_variables``)."""
+        w = self.get_weights()
+        n = 2 * len(self.dense_layers)
+        w[:n] = [np.asarray(a, np.float32) for a in arrays[:n]]
+        if self.batch_normalization:
+            w[n:n + 2] = [np.asarray(a, np.float32) for a in arrays[n:n + 2]]
+        self.set_weights(w)
+
+    def update_moving_statistics(self, batch_stats):
+        """Keras: moving <- moving * momentum + batch * (1 - momentum), once per BatchNormalization call (``batch_stats`` has
+        one [2, F] row per call, in call order)."""
+        if not self.batch_normalization:
+            return
+        bn = self.layers[-1]
+        mean, var = bn.moving_mean.astype(np.float64), bn.moving_variance.astype(np.float64)
+        for mu, v in np.asarray(batch_stats, np.float64).reshape(-1, 2, mean.shape[0]):
+            mean = mean * bn.momentum + mu * (1 - bn.momentum)
+            var = var * bn.momentum + v * (1 - bn.momentum)
+        w = self.get_weights()
+        w[-2], w[-1] = mean.astype(np.float32), var.astype(np.float32)
+        self.set_weights(w)
+
     def device_mlp(self, device: int = 0):
         from GNN import _engine
         if self._device is None:

@@ -254,6 +254,17 @@ class GraphTensor:
             raise ValueError('edge-based GNN needs set_mask / output_mask over the arcs (problem_based == \'a\')')
         return entry_dst, self.arcs[:, 2:], mask
 
+    def adjacency_by_source(self):
+        """Adjacency (untransposed) as CSR over SOURCE nodes, destinations ascending: the operand of the transposed
+        aggregation in the backward pass (d state[src] += w * d agg[dst])."""
+        indptr, src, w = self.Adjacency
+        n = len(indptr) - 1
+        dst = np.repeat(np.arange(n), np.diff(indptr))
+        order = np.lexsort((dst, src))
+        sip = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum(np.bincount(src, minlength=n), out=sip[1:])
+        return sip, dst[order].astype(np.int32), np.asarray(w, np.float32)[order]
+
     def nodegraph_csr(self):
         """NodeGraph^T as CSR over graphs, ascending node inside a graph (input of gnn_loop_readout)."""
         ng = self.NodeGraph

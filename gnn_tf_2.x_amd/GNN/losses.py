@@ -27,3 +27,15 @@ def mean_squared_error(y_true, y_pred, **_):
 
 
 mse = mean_squared_error
+
+
+def device_loss_kind(fn, loss_args) -> int:
+    """Loss code of gnn_loop_train_step for the callables above (0 categorical_crossentropy, 1 mean_squared_error)."""
+    if fn is categorical_crossentropy:
+        if loss_args.get('from_logits', False):
+            raise NotImplementedError('categorical_crossentropy(from_logits=True) is not implemented for training on the device')
+        return 0
+    if fn is mean_squared_error:
+        return 1
+    raise NotImplementedError(f'training with loss {getattr(fn, "__name__", fn)!r} is not implemented on the MI355X engine '
+                              f'(available: GNN.losses.categorical_crossentropy, GNN.losses.mean_squared_error)')

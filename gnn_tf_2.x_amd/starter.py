@@ -4,7 +4,8 @@ names (`graphs, gTr, gVa, gTe, gnn, lgnn`), models running on the MI355X engine.
     cd gnn_tf_2.x_amd && python -i starter.py
     >>> gnn.test(gTe)            # forward Loop / evaluate / test run on the GPU
     >>> lgnn.test(gTe)
-Training (`gnn.train`, `lgnn.train`, `LKO`) needs the backward pass, which the engine does not provide yet.
+    >>> gnn.train(gTr, 20, gVa)  # gradients on the GPU (gnn_loop_train_step), Adam on the host
+`lgnn.train` supports training_mode='serial'; the joint modes are not implemented yet.
 """
 from __future__ import annotations
 
@@ -16,7 +17,7 @@ from numpy import random
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from GNN import GNN_metrics as mt, GNN_utils as utils, losses
+from GNN import GNN_metrics as mt, GNN_utils as utils, losses, optimizers
 from GNN.GNN import GNNnodeBased, GNNedgeBased, GNNgraphBased
 from GNN.LGNN import LGNN
 from GNN.MLP import MLP, get_inout_dims
@@ -65,7 +66,7 @@ layers: int = 5
 get_state: bool = False
 get_output: bool = True
 path_writer: str = 'writer/'
-optimizer = None                                   # tf.optimizers.Adam(learning_rate=0.001) in the reference: unused without train()
+optimizer = optimizers.Adam(learning_rate=0.001)
 lossF = losses.categorical_crossentropy
 lossArguments: Optional[dict] = {'from_logits': False}
 extra_metrics: Optional[dict] = {i: mt.Metrics[i] for i in ['Acc', 'Bacc', 'Tpr', 'Tnr', 'Fpr', 'Fnr', 'Ck', 'Js', 'Prec', 'Rec', 'Fs']}

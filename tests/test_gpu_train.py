@@ -83,3 +83,56 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
                            dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], seed=5,
                            bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]), max_iter=max_it)
     assert np.isfinite(res2['loss']) and all(np.isfinite(a).all() for a in res2['grads_state'] + res2['grads_output'])
+
+
+def test_train_loop_reduces_loss_and_keeps_history():
+    """BaseClass.train end to end (reference GNN_BaseClass.py:192-335): Adam on device gradients must fit a learnable
+    node-classification task; history bookkeeping, early-stopping restore, graph-based variant, serial LGNN."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNnodeBased, GNNgraphBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import MLP, set_seed
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(0)
+    set_seed(0)
+    graphs = []
+    for _ in range(6):
+        n = 120
+        arcs = random_arcs(rng, n, 360, 1)
+        nodes = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+        cls = (nodes[:, 0] + 0.5 * nodes[:, 1] > 0).astype(int)          # learnable from the labels
+        graphs.append(GraphObject(arcs=arcs, nodes=nodes, targets=np.eye(2)[cls]))
+    gTr, gVa = graphs[:4], GraphObject.merge(graphs[4:], problem_based='n', aggregation_mode='average')
+
+    def model(cls_, layer=0):
+        st = MLP(1 + 2 * (3 + 2 * (layer > 0)), [8, 3 + 2 * (layer > 0)], 'tanh', 'glorot_normal', 'zeros', dropout_rate=0.1, dropout_pos=0)
+        ou = MLP(3 + 2 * (layer > 0), [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
+        return cls_(net_state=st, net_output=ou, optimizer=optimizers.Adam(0.02), loss_function=losses.categorical_crossentropy,
+                    loss_arguments=None, state_vect_dim=0, max_iteration=4, threshold=0.01, addressed_problem='c',
+                    extra_metrics={'Acc': lambda yt, yp: float(np.mean(yt == yp))})
+
+    gnn = model(GNNnodeBased)
+    before = gnn.test(gVa)
+    gnn.train(gTr, 40, gVa, update_freq=5, max_fails=50, verbose=0)
+    after = gnn.test(gVa)
+    assert after['Loss'] < 0.6 * before['Loss'] and after['Acc'] > 0.85
+    h = gnn.history
+    assert h['Epoch'] == list(range(0, 40, 5)) and len(h['Loss Tr']) == len(h['Loss Va']) == len(h['Fail']) == 8
+    assert h['Best Loss Va'][-1] == min(h['Loss Va']) and h['Loss Tr'][-1] < h['Loss Tr'][0]
+    gnn.train(gTr, 5, gVa, update_freq=5, max_fails=50, verbose=0)      # re-entrant: epochs continue (reference :278-279)
+    assert gnn.history['Epoch'][-1] == 40
+    # graph-based: 2 graphs per batch, targets per graph
+    gg = []
+    for i in range(8):
+        n = 40
+        nodes = (2 * rng.random((n, 3)) - 1).astype(np.float32) + (0.8 if i % 2 else -0.8)
+        gg.append(GraphObject(arcs=random_arcs(rng, n, 100, 1), nodes=nodes, targets=np.eye(2)[[i % 2]], problem_based='g'))
+    batches = [GraphObject.merge(gg[i:i + 4], problem_based='g', aggregation_mode='average') for i in (0, 4)]
+    ggnn = model(GNNgraphBased)
+    l0 = ggnn.test(batches)['Loss']
+    ggnn.train(batches, 30, None, update_freq=10, verbose=0)
+    assert ggnn.test(batches)['Loss'] < 0.7 * l0
+    # serial LGNN training (reference LGNN.py:325-340)
+    lgnn = LGNN([model(GNNnodeBased, 0), model(GNNnodeBased, 1)], False, True, optimizers.Adam(0.02), losses.categorical_crossentropy, None, 'c')
+    lgnn.train(gTr, 10, None, update_freq=5, training_mode='serial', verbose=0)
+    assert lgnn.test(gVa)['Loss'] < before['Loss']

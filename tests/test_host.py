@@ -140,8 +140,13 @@ def test_model_argument_errors_match_reference():
     assert BaseClass.checktype(None) is None
     gnn = mk()
     assert gnn.get_weights()[0][0][0].shape == (7, 3)
+    from GNN.GNN import GNNedgeBased
     with pytest.raises(NotImplementedError):
-        gnn.train([], 1)
+        GNNedgeBased.training_step(gnn, None, True)
+    lg = LGNN([gnn], False, True, None, None, None, 'c')
+    with pytest.raises(NotImplementedError):
+        lg.train([], 1, training_mode='parallel')
+    assert st.dropout_rates() == [0.0, 0.0] and MLP(7, [5, 3], 'selu', 'zeros', 'zeros', dropout_rate=0.1, dropout_pos=[0, 1]).dropout_rates() == [0.1, 0.1, 0.0]
 
 
 def test_library_exports_every_declared_symbol():
