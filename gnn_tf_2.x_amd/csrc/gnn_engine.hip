@@ -211,19 +211,38 @@ __global__ void __launch_bounds__(256) k_check(int64_t n_rows, int d, const floa
                                                const float *__restrict__ so, float thr, int *flag_out, const int *gate,
                                                int world)
 {
-    __shared__ float ts[256 * 33], to[256 * 33];
+    extern __shared__ float chk_sh[];                      // ts [256 * 33] (+ to [256 * 33] iff so)
+    float *ts = chk_sh, *to = chk_sh + 256 * 33;
     if (!gnn_gate_open(gate, world)) return;
     const int64_t r0 = (int64_t)blockIdx.x * 256;
     const int64_t i = r0 + threadIdx.x;
     float dist = 0.0f, nrm = 0.0f;
+    const bool v4 = (d & 3) == 0;
     for (int c0 = 0; c0 < d; c0 += 32) {
         const int cw = (d - c0) < 32 ? (d - c0) : 32;
         __syncthreads();
-        for (int t = threadIdx.x; t < 256 * 32; t += 256) {
-            const int r = t >> 5, c = t & 31;
-            if (c < cw && r0 + r < n_rows) {
-                ts[r * 33 + c] = s[(r0 + r) * d + c0 + c];
-                if (so) to[r * 33 + c] = so[(r0 + r) * d + c0 + c];
+        if (v4) {
+#pragma unroll
+            for (int t = threadIdx.x; t < 256 * 8; t += 256) {
+                const int r = t >> 3, c = (t & 7) * 4;
+                if (c < cw && r0 + r < n_rows) {
+                    const float4 a = *reinterpret_cast<const float4 *>(s + (r0 + r) * d + c0 + c);
+                    float *p = ts + r * 33 + c;
+                    p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w;
+                    if (so) {
+                        const float4 b = *reinterpret_cast<const float4 *>(so + (r0 + r) * d + c0 + c);
+                        float *q = to + r * 33 + c;
+                        q[0] = b.x; q[1] = b.y; q[2] = b.z; q[3] = b.w;
+                    }
+                }
+            }
+        } else {
+            for (int t = threadIdx.x; t < 256 * 32; t += 256) {
+                const int r = t >> 5, c = t & 31;
+                if (c < cw && r0 + r < n_rows) {
+                    ts[r * 33 + c] = s[(r0 + r) * d + c0 + c];
+                    if (so) to[r * 33 + c] = so[(r0 + r) * d + c0 + c];
+                }
             }
         }
         __syncthreads();
@@ -298,6 +317,72 @@ __global__ void k_feats_edge(int64_t n_masked, const int32_t *__restrict__ rows,
         v = arc_labels[e * AL + (c - 2 * wn)];
     }
     feats[t] = v;
+}
+
+// apply_filters + a ONE-layer net_output with few outputs (the usual classifier head, T <= 8) in one pass over the masked
+// rows.  A block stages 64 feature rows [state | labels] through LDS with coalesced reads, then thread (row, j) runs the
+// k-ordered fmaf chain of output j (same order as k_dense); softmax / activation / BatchNormalization as k_softmax_bn.
+// Saves materialising [M, NL + D] features and two more launches.
+#define GNN_OUT1_ROWS 64
+__global__ void k_out1(int64_t n_masked, const int32_t *__restrict__ masked_rows, const float *s0, const float *s1,
+                       const int *kfinal, int Ds, const float *__restrict__ nodes_own, int NL, int NLc,
+                       const float *__restrict__ W, const float *__restrict__ b, int T, int act,
+                       const float *__restrict__ bn_scale, const float *__restrict__ bn_shift, float *__restrict__ out)
+{
+    extern __shared__ float osh[];
+    const int wf = Ds + NLc, ldw = wf | 1;
+    float *wsh = osh;                                      // W [wf, T] then b [T]
+    float *tile = wsh + (wf + 1) * T;                      // [64, ldw]
+    float *vsh = tile + GNN_OUT1_ROWS * ldw;               // [64, T]
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const float *state = ((*kfinal) & 1) ? s1 : s0;
+    const int64_t base = (int64_t)blockIdx.x * GNN_OUT1_ROWS;
+    for (int t = tid; t < (wf + 1) * T; t += nthr) wsh[t] = t < wf * T ? W[t] : b[t - wf * T];
+    if ((Ds & 3) == 0) {                                   // 16-byte pieces of the state rows, many rows in flight per thread
+        const int q = Ds >> 2;
+#pragma unroll 4
+        for (int idx = tid; idx < GNN_OUT1_ROWS * q; idx += nthr) {
+            const int r = idx / q, c = (idx - r * q) * 4;
+            if (base + r < n_masked) {
+                const float4 v = *reinterpret_cast<const float4 *>(state + (int64_t)masked_rows[base + r] * Ds + c);
+                float *t = tile + r * ldw + c;
+                t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < GNN_OUT1_ROWS * Ds; idx += nthr) {
+            const int r = idx / Ds, c = idx - r * Ds;
+            if (base + r < n_masked) tile[r * ldw + c] = state[(int64_t)masked_rows[base + r] * Ds + c];
+        }
+    }
+    for (int idx = tid; idx < GNN_OUT1_ROWS * NLc; idx += nthr) {
+        const int r = idx / NLc, c = idx - r * NLc;
+        if (base + r < n_masked) tile[r * ldw + Ds + c] = nodes_own[(int64_t)masked_rows[base + r] * NL + c];
+    }
+    __syncthreads();
+    const int r = tid / T, j = tid - r * T;
+    const int64_t m = base + r;
+    const bool live = r < GNN_OUT1_ROWS && m < n_masked;
+    if (live) {
+        float acc = 0.0f;
+        const float *x = tile + r * ldw;
+        for (int k = 0; k < wf; ++k) acc = __builtin_fmaf(x[k], wsh[k * T + j], acc);
+        vsh[r * T + j] = acc + wsh[wf * T + j];
+    }
+    __syncthreads();
+    if (!live) return;
+    const float *y = vsh + r * T;
+    float v;
+    if (act == GNN_ACT_SOFTMAX) {
+        float mx = y[0];
+        for (int q = 1; q < T; ++q) mx = y[q] > mx ? y[q] : mx;
+        float sum = 0.0f, mine = 0.0f;
+        for (int q = 0; q < T; ++q) { const float e = gnn_expf(y[q] - mx); sum = sum + e; if (q == j) mine = e; }
+        v = __fdiv_rn(mine, sum);
+    } else
+        v = gnn_act(y[j], act);
+    if (bn_scale) { const float t2 = v * bn_scale[j]; v = t2 + bn_shift[j]; }
+    out[m * T + j] = v;
 }
 
 // graph readout: out_graph[g, t] = sum over the stored (node, w) of graph g, ascending node, fmaf(w, out_nodes[node, t])
@@ -405,12 +490,23 @@ int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float
     return GNN_OK;
 }
 
-int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base)
+static int launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_out,
+                        const int *gate, int world)
 {
     if (n_rows == 0) return GNN_OK;
-    hipLaunchKernelGGL(k_check, cdiv(n_rows, 256), 256, 0, st, n_rows, d, s, so, thr, flag_rank_base, (const int *)nullptr, 1);
+    static bool big_lds = false;                           // two staged tiles are 66 KB of dynamic LDS
+    if (!big_lds) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_check), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4));
+        big_lds = true;
+    }
+    hipLaunchKernelGGL(k_check, cdiv(n_rows, 256), 256, sizeof(float) * 256 * 33 * (so ? 2 : 1), st, n_rows, d, s, so, thr, flag_out, gate, world);
     HIPCHK(hipGetLastError());
     return GNN_OK;
+}
+
+int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base)
+{
+    return launch_check(st, n_rows, d, s, so, thr, flag_rank_base, nullptr, 1);
 }
 
 // Sequential forward on device buffers: X[n, dims[0]] (ldx) -> Y[n, dims.back()] (ldy); t0/t1: [n, max hidden width]
@@ -910,12 +1006,7 @@ static int unfused_iteration(gnn_loop *l, int k)
     rc = launch_mlp(l->stream, l->st, g->n_rows, l->inp, l->in_s, own_nxt, l->Ds, l->tmp[0], l->tmp[1], gate, P);
     if (rc) return rc;
     // condition for the next body (GNN.py:206-218)
-    if (g->n_rows) {
-        hipLaunchKernelGGL(k_check, cdiv(g->n_rows, 256), 256, 0, l->stream, g->n_rows, l->Ds, own_nxt, own_cur, l->thr,
-                           l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS, gate, P);
-        HIPCHK(hipGetLastError());
-    }
-    return GNN_OK;
+    return launch_check(l->stream, g->n_rows, l->Ds, own_nxt, own_cur, l->thr, l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS, gate, P);
 }
 
 // Everything one Loop puts on the stream between the first condition and net_output.  Bodies are enqueued without waiting
@@ -934,11 +1025,7 @@ static int loop_enqueue(gnn_loop *l, bool fused)
         HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->row_begin * g->NL,
                               sizeof(float) * (size_t)g->n_rows * l->Ds, hipMemcpyDeviceToDevice, st));
     // first condition: state vs ones (GNN.py:266, :271)
-    if (g->n_rows) {
-        hipLaunchKernelGGL(k_check, cdiv(g->n_rows, 256), 256, 0, st, g->n_rows, l->Ds, own0, (const float *)nullptr, l->thr,
-                           l->flags + (size_t)l->rank * GNN_FLAG_WORDS, (const int *)nullptr, 1);
-        HIPCHK(hipGetLastError());
-    }
+    if ((rc = launch_check(st, g->n_rows, l->Ds, own0, nullptr, l->thr, l->flags + (size_t)l->rank * GNN_FLAG_WORDS, nullptr, 1))) return rc;
     if ((rc = loop_allgather(l, l->state[0], l->flags))) return rc;
 
     // loop-invariant aggregates (GNN.py:259, :263)
@@ -988,7 +1075,15 @@ static int loop_enqueue(gnn_loop *l, bool fused)
         return GNN_OK;
     }
     // apply_filters + net_output on the owned masked rows (GNN.py:275-279)
-    if (g->n_masked) {
+    const size_t out1_lds = sizeof(float) * ((size_t)(l->wf + 1) * l->T + (size_t)GNN_OUT1_ROWS * (l->wf | 1) + (size_t)GNN_OUT1_ROWS * l->T);
+    if (g->n_masked && l->ou->n_layers == 1 && l->T <= 8 && out1_lds <= 64 * 1024) {
+        const gnn_mlp *ou = l->ou;
+        hipLaunchKernelGGL(k_out1, cdiv(g->n_masked, GNN_OUT1_ROWS), GNN_OUT1_ROWS * l->T < 64 ? 64 : GNN_OUT1_ROWS * l->T, out1_lds, st, g->n_masked, g->sh->masked_rows,
+                           l->state[0] + (size_t)g->row_begin * l->Ds, l->state[1] + (size_t)g->row_begin * l->Ds, l->kfinal_dev, l->Ds,
+                           g->nodes + (size_t)g->row_begin * g->NL, g->NL, l->NLc, ou->W[0], ou->b[0], l->T, ou->acts[0],
+                           ou->has_bn ? ou->bn_scale : (const float *)nullptr, ou->has_bn ? ou->bn_shift : (const float *)nullptr, l->out);
+        HIPCHK(hipGetLastError());
+    } else if (g->n_masked) {
         const int64_t tot = g->n_masked * l->wf;
         hipLaunchKernelGGL(k_feats, cdiv(tot, 256), 256, 0, st, g->n_masked, g->sh->masked_rows, l->state[0] + (size_t)g->row_begin * l->Ds,
                            l->state[1] + (size_t)g->row_begin * l->Ds, l->kfinal_dev, l->Ds, g->nodes + (size_t)g->row_begin * g->NL, g->NL, l->NLc, l->feats);

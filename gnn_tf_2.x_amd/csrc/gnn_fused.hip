@@ -195,7 +195,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     }
     const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, (n_tiles + GNN_FUSED_WAVES - 1) / GNN_FUSED_WAVES);
     a.tile_ctr = l->tile_ctr + k;
-    static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : 5;   // tuning experiments
+    static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : 0;   // tuning experiments
     a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_env : 0;   // only when every wave has several tiles to run
     const size_t lds = lds_bytes(p);
     bool ok = false;
