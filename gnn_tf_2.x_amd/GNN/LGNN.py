@@ -165,5 +165,102 @@ class LGNN(BaseClass):
                 gTr1 = [self.update_graph(g, *node_loop(gt)[1:]) for g, gt in zip(gTr0, gTr1)]
                 if gVa0: gVa1 = [self.update_graph(g, *node_loop(gt)[1:]) for g, gt in zip(gVa0, gVa1)]
             return
-        raise NotImplementedError("LGNN.train(training_mode='parallel' | 'residual'): joint back-propagation through the stack is "
-                                  "not implemented on the MI355X engine yet (training_mode='serial' is)")
+        # 'parallel' / 'residual': one joint step per batch (reference LGNN.py:343-344 -> GNN_BaseClass.train)
+        super().train(gTr, epochs, gVa, update_freq, max_fails, observed_metric, policy, mean=mean, verbose=verbose)
+
+    def training_step(self, g: GraphTensor, mean: bool, *, state0=None, masks_state=None, masks_output=None) -> dict:
+        """Joint step of the whole stack (reference GNN_BaseClass.py:231-247 around LGNN.py:201-224): training-mode forward
+        of every layer (``gnn_loop_train_forward``), loss = mean of the per-layer losses ('parallel') or loss of the mean
+        output ('residual'), then the backward passes from the last layer to the first (``gnn_loop_train_backward``); layer
+        i also receives the gradient that reaches it through the labels of layer i + 1 (update_graph, LGNN.py:227-260).
+        ``state0`` / ``masks_*``: optional per-layer lists (tests inject them)."""
+        from GNN import losses, _engine
+        if self.GNNS_TYPE == GNNedgeBased:
+            raise NotImplementedError('edge-based LGNN is not implemented on the MI355X engine yet')
+        if self.training_mode not in ('parallel', 'residual'):
+            raise ValueError("training_step is the joint step of training_mode 'parallel' / 'residual'")
+        if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
+        for layer in self.get_dense_layers():
+            if layer.kernel_regularizer is not None or layer.bias_regularizer is not None:
+                raise NotImplementedError('kernel/bias regularizers are not implemented for training on the MI355X engine')
+        if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
+            raise TypeError('train() needs an optimizer with apply_gradients, e.g. GNN.optimizers.Adam()')
+        kind = losses.device_loss_kind(self.loss_function, self.loss_args)
+        graph_based = self.GNNS_TYPE == GNNgraphBased
+        if graph_based and not g.loop_mask().all():
+            raise ValueError('graph-based GNN needs set_mask and output_mask all True')
+        L = self.LAYERS
+        state0 = state0 or [None] * L
+        masks_state = masks_state or [None] * L
+        masks_output = masks_output or [None] * L
+        targets = self.GNNS_TYPE.get_filtered_tensor(g, g.targets)
+        weights = self.GNNS_TYPE.get_filtered_tensor(g, g.sample_weights)
+        if not hasattr(g, '_by_source'):
+            g._by_source = g.adjacency_by_source()
+        base = g.device_graph(self.gnns[0].device)
+        derived = g.__dict__.setdefault('_lgnn_graphs', {})
+        mask = g.loop_mask()
+        NLb = np.asarray(g.nodes).shape[1]
+        # ---- forward ----
+        current, loops, K, outs = base, [], [], []
+        for idx, gnn in enumerate(self.gnns):
+            loop = gnn._device_loop(current)
+            if gnn.state_vect_dim > 0:
+                gnn.seed += 1
+                loop.set_state0(state0[idx], gnn.seed)
+            gnn._train_calls = getattr(gnn, '_train_calls', 0) + 1
+            k, out_nodes = loop.train_forward(gnn.net_state.device_mlp(gnn.device), gnn.net_output.device_mlp(gnn.device), g._by_source,
+                                              dropout_state=gnn.net_state.dropout_rates(), dropout_output=gnn.net_output.dropout_rates(),
+                                              masks_state=masks_state[idx], masks_output=masks_output[idx],
+                                              seed=gnn.seed * 1000003 + gnn._train_calls, bn_state=gnn.net_state.bn_gamma_beta(),
+                                              bn_output=gnn.net_output.bn_gamma_beta())
+            loops.append(loop); K.append(k)
+            outs.append(loop.readout(*g.nodegraph_csr()) if graph_based else out_nodes)
+            if idx < L - 1:
+                extra = self.get_state * loop.Ds + self.get_output * loop.T
+                nxt = derived.get(extra)
+                if nxt is None:
+                    nxt = derived[extra] = base.derive(extra)
+                nxt.update_labels(base, loop, self.get_state, self.get_output)
+                current = nxt
+        # ---- loss (reference LGNN.py:219-222) ----
+        if self.training_mode == 'residual':
+            loss, d = _engine.loss_grad(kind, targets, np.mean(outs, axis=0, dtype=np.float32), weights)
+            d_outs = [d / L] * L
+        else:
+            pairs = [_engine.loss_grad(kind, targets, o, weights) for o in outs]
+            loss = float(np.mean([p[0] for p in pairs]))
+            d_outs = [p[1] / L for p in pairs]
+        # ---- backward, last layer first ----
+        ng = np.asarray(g.NodeGraph, dtype=np.float32) if graph_based else None
+        results = [None] * L
+        d_state_extra = d_out_extra = None
+        for idx in reversed(range(L)):
+            d_nodes_out = ng @ d_outs[idx] if graph_based else d_outs[idx]
+            if d_out_extra is not None: d_nodes_out = d_nodes_out + d_out_extra
+            res = results[idx] = loops[idx].train_backward(d_nodes_out, d_state_extra, want_d_nodes=idx > 0 and (self.get_state or self.get_output))
+            d_state_extra = d_out_extra = None
+            if idx > 0 and res['d_nodes'] is not None:
+                prev, c = loops[idx - 1], NLb
+                if self.get_state:
+                    d_state_extra = res['d_nodes'][:, c:c + prev.Ds]
+                    c += prev.Ds
+                if self.get_output:
+                    d_out_extra = res['d_nodes'][mask, c:c + prev.T]
+        # ---- update: net_state gradients / k when mean (GNN_BaseClass.py:241); one optimizer over all layers (:244-247) ----
+        gs = [[a / k for a in r['grads_state']] if (mean and k) else r['grads_state'] for r, k in zip(results, K)]
+        go = [r['grads_output'] for r in results]
+        ws, wo = self.trainable_variables()
+        dW = [a for layer in gs + go for a in layer]
+        W = [a for layer in ws + wo for a in layer]
+        assert len(dW) == len(W)
+        new = self.optimizer.apply_gradients(zip(dW, W))
+        pos = 0
+        for net in [gnn.net_state for gnn in self.gnns] + [gnn.net_output for gnn in self.gnns]:
+            n = len(net.trainable_variables)
+            net.set_trainable(new[pos:pos + n])
+            pos += n
+        for gnn, r, loop in zip(self.gnns, results, loops):
+            gnn.net_state.update_moving_statistics(r['bn_batch_state'])
+            if loop.n_masked: gnn.net_output.update_moving_statistics(r['bn_batch_output'])
+        return dict(loss=loss, k=K, grads_state=[r['grads_state'] for r in results], grads_output=go, outs=outs)

@@ -18,6 +18,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_graph_derive', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
+           'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loss_grad',
            'gnn_loop_set_impl', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy']
 
@@ -41,6 +42,16 @@ def lib():
             if name != 'gnn_last_error':
                 getattr(_lib, name).restype = C.c_int
     return _lib
+
+
+def loss_grad(loss_kind: int, targets, out, sample_weights):
+    """gnn_loss_grad: (sum_i w_i L(t_i, out_i), d / d out) for loss_kind 0 categorical_crossentropy / 1 mean_squared_error."""
+    t, o, w = _f32(targets), _f32(out), _f32(sample_weights)
+    if t.shape != o.shape or w.shape != (o.shape[0],): raise ValueError(f'targets {t.shape}, outputs {o.shape}, weights {w.shape} do not match')
+    d = np.zeros_like(o)
+    loss = C.c_double()
+    _check(lib().gnn_loss_grad(C.c_int(loss_kind), C.c_int64(o.shape[0]), C.c_int(o.shape[1]), _fp(t), _fp(o), _fp(w), C.byref(loss), _fp(d)))
+    return float(loss.value), d
 
 
 def _check(rc: int):
@@ -326,6 +337,62 @@ class Loop:
         kk = int(k.value)
         return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
                     bn_batch_state=bns[:kk], bn_batch_output=bno)
+
+    @staticmethod
+    def _grad_shapes(net: 'Mlp'):
+        out = []
+        for l in range(net.n):
+            out += [(int(net.dims[l]), int(net.dims[l + 1])), (int(net.dims[l + 1]),)]
+        if net.batch_normalization:
+            out += [(int(net.dims[-1]),), (int(net.dims[-1]),)]
+        return out
+
+    def train_forward(self, net_state: 'Mlp', net_output: 'Mlp', src_csr, dropout_state=None, dropout_output=None,
+                      masks_state=None, masks_output=None, seed: int = 0, bn_state=None, bn_output=None):
+        """gnn_loop_train_forward: training-mode Loop; returns (k, node-level outputs [n_masked, T]).  The loop's state() /
+        output() / readout() then hold the training-mode results, and train_backward() may be called once."""
+        sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2]))
+        ds_ = _f32(dropout_state if dropout_state is not None else np.zeros(net_state.n + 1))
+        do_ = _f32(dropout_output if dropout_output is not None else np.zeros(net_output.n + 1))
+        ms = np.ascontiguousarray(masks_state, np.uint8) if masks_state is not None else None
+        mo = np.ascontiguousarray(masks_output, np.uint8) if masks_output is not None else None
+        u8 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8)) if a is not None else None
+        bs = _f32(bn_state) if bn_state is not None else None
+        bo = _f32(bn_output) if bn_output is not None else None
+        k = C.c_float()
+        out = np.zeros((self.n_masked, self.T), np.float32)
+        _check(lib().gnn_loop_train_forward(self._h, _ip(sip), _ip(sdst), _fp(sw), _fp(ds_), _fp(do_), u8(ms), u8(mo), C.c_uint64(seed),
+                                            _fp(bs), _fp(bo), C.byref(k), _fp(out)))
+        self._train_nets = (net_state, net_output, int(k.value))
+        return float(k.value), out
+
+    def train_backward(self, d_out_nodes, d_state_extra=None, want_d_nodes: bool = False):
+        """gnn_loop_train_backward: dict(grads_state, grads_output (raw sums over the iterations), bn_batch_state,
+        bn_batch_output, d_nodes [N, NL] or None)."""
+        net_state, net_output, kk = self._train_nets
+        shp_s, shp_o = self._grad_shapes(net_state), self._grad_shapes(net_output)
+        gs = np.zeros(sum(int(np.prod(x)) for x in shp_s), np.float32)
+        go = np.zeros(sum(int(np.prod(x)) for x in shp_o), np.float32)
+        bns = np.zeros((max(1, kk), 2, int(net_state.dims[-1])), np.float32)
+        bno = np.zeros((2, int(net_output.dims[-1])), np.float32)
+        d_out = _f32(d_out_nodes)
+        if d_out.shape != (self.n_masked, self.T): raise ValueError(f'd_out_nodes shape {d_out.shape} != {(self.n_masked, self.T)}')
+        dse = None
+        if d_state_extra is not None:
+            dse = _f32(d_state_extra)
+            if dse.shape != (self.n_rows, self.Ds): raise ValueError(f'd_state_extra shape {dse.shape} != {(self.n_rows, self.Ds)}')
+        dn = np.zeros((self.n_rows, self.graph.dims()['NL']), np.float32) if want_d_nodes else None
+        _check(lib().gnn_loop_train_backward(self._h, _fp(d_out), _fp(dse), _fp(gs), _fp(go), _fp(bns), _fp(bno), _fp(dn)))
+
+        def split(flat, shp):
+            out, off = [], 0
+            for x in shp:
+                cnt = int(np.prod(x))
+                out.append(flat[off:off + cnt].reshape(x).copy())
+                off += cnt
+            return out
+
+        return dict(grads_state=split(gs, shp_s), grads_output=split(go, shp_o), bn_batch_state=bns[:kk], bn_batch_output=bno, d_nodes=dn)
 
     def set_impl(self, impl: int) -> int:
         used = C.c_int(0)

@@ -163,6 +163,7 @@ struct gnn_loop {
     hipEvent_t ev_total[2] = {nullptr, nullptr};
     float total_ms = 0.f, avg_iter_ms = 0.f;
     int n_iter_timed = 0;
+    void *train_ctx = nullptr;              // gnn_train.hip: what train_forward leaves for train_backward
 };
 
 // gnn_engine.hip
@@ -172,6 +173,9 @@ int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const
 int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float *X, int64_t ldx, const float *W, const float *b,
                      int act, float *Y, int64_t ldy);
 int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base);
+
+// gnn_train.hip
+void gnn_train_ctx_free(gnn_loop *l);
 
 // gnn_fused.hip
 bool gnn_fused_supported(const gnn_loop *l);

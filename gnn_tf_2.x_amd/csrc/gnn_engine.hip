@@ -1256,6 +1256,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
 {
     if (!l) return GNN_OK;
     (void)hipSetDevice(l->device);
+    gnn_train_ctx_free(l);
     for (int b = 0; b < 2; ++b) { (void)hipFree(l->state[b]); (void)hipFree(l->tmp[b]); (void)hipFree(l->otmp[b]); }
     (void)hipFree(l->inp); (void)hipFree(l->inv); (void)hipFree(l->state_init); (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->flags); (void)hipFree(l->kfinal_dev); (void)hipFree(l->tile_ctr);
     if (l->kfinal_host) (void)hipHostFree(l->kfinal_host);

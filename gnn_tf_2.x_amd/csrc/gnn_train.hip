@@ -406,40 +406,92 @@ void loss_host(int kind, int64_t n, int T, const float *t, const float *o, const
     *loss = total;
 }
 
+// d_nodes[r, c] += d_inp[r, c_nodes + c] + via[r, c]   (direct label columns of the concat + transposed aggregated_nodes)
+__global__ void k_nodes_grad(int64_t n, int NL, const float *d_inp, int in_s, int c_nodes, const float *via, float *d_nodes)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * NL) return;
+    const int64_t r = t / NL;
+    const int c = (int)(t - r * NL);
+    d_nodes[t] += d_inp[r * in_s + c_nodes + c] + via[t];
+}
+
+// d_nodes[rows[q], c] += d_feats[q, Ds + c]   (label columns of net_output's input; rows are unique)
+__global__ void k_scatter_label_grad(int64_t m, const int32_t *rows, const float *d_feats, int wf, int Ds, int NL, float *d_nodes)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * NL) return;
+    const int64_t q = t / NL;
+    const int c = (int)(t - q * NL);
+    d_nodes[(int64_t)rows[q] * NL + c] += d_feats[q * wf + Ds + c];
+}
+
+__global__ void k_axpy1(int64_t n, const float *x, float *y)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) y[t] += x[t];
+}
+
+// What gnn_loop_train_forward leaves for gnn_loop_train_backward (owned by the loop; replaced by the next forward)
+struct TrainCtx {
+    Buf buf;
+    Net ns, no_;
+    std::vector<NetCache> caches;
+    NetCache co;
+    int32_t *d_sip = nullptr, *d_sdst = nullptr;
+    float *d_sw = nullptr;
+    float *state = nullptr, *out_nodes = nullptr;
+    int k = 0;
+};
+
 }   // namespace
 
-extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
-                                   const float *targets, const float *sample_weights, int64_t n_targets, int loss_kind,
-                                   int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w,
-                                   const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
-                                   const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
-                                   float *loss_out, float *k_out, float *grads_state, float *grads_output,
-                                   float *bn_batch_state, float *bn_batch_output)
+void gnn_train_ctx_free(gnn_loop *l)
 {
-    ARGCHK(l && src_indptr && targets && sample_weights && dropout_state && dropout_output && loss_out && k_out && grads_state && grads_output,
-           "bad arguments");
-    ARGCHK(l->world == 1 && !l->edge_mode && !l->edge_expected, "training is single-GPU, node/graph-based only");
+    if (l && l->train_ctx) {
+        delete static_cast<TrainCtx *>(l->train_ctx);
+        l->train_ctx = nullptr;
+    }
+}
+
+extern "C" int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets, const float *out, const float *sample_weights,
+                             double *loss, float *d_out)
+{
+    ARGCHK((n_rows == 0 || (targets && out && sample_weights)) && loss && n_out > 0 && n_rows >= 0, "bad arguments");
     ARGCHK(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error");
+    std::vector<float> d;
+    loss_host(loss_kind, n_rows, n_out, targets, out, sample_weights, loss, d);
+    if (d_out && n_rows) memcpy(d_out, d.data(), sizeof(float) * d.size());
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
+                                      const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
+                                      const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
+                                      float *k_out, float *out_nodes_host)
+{
+    ARGCHK(l && src_indptr && dropout_state && dropout_output && k_out, "bad arguments");
+    ARGCHK(l->world == 1 && !l->edge_mode && !l->edge_expected, "training is single-GPU, node/graph-based only");
     ARGCHK(!l->st->has_bn || bn_state, "net_state ends with BatchNormalization: gamma|beta required");
     ARGCHK(!l->ou->has_bn || bn_output, "net_output ends with BatchNormalization: gamma|beta required");
     if (!l->have_state0 && l->D) return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
     gnn_graph *g = l->g;
     const int64_t N = g->n_rows, M = g->n_masked, E = g->E;
     const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->wf;
-    ARGCHK(n_targets == (n_graphs > 0 ? n_graphs : M), "%lld target rows but %lld outputs", (long long)n_targets, (long long)(n_graphs > 0 ? n_graphs : M));
     HIPCHK(hipSetDevice(l->device));
     hipStream_t st = l->stream;
-    Buf buf;
+    gnn_train_ctx_free(l);
+    TrainCtx *cx = new TrainCtx();
+    l->train_ctx = cx;
+    Buf &buf = cx->buf;
+    Net &ns = cx->ns, &no_ = cx->no_;
     int rc;
-    Net ns, no_;
     if ((rc = net_setup(buf, ns, l->st, dropout_state, bn_state)) || (rc = net_setup(buf, no_, l->ou, dropout_output, bn_output))) return rc;
     // Adjacency by source for the transposed aggregation of the backward pass
-    int32_t *d_sip = nullptr, *d_sdst = nullptr;
-    float *d_sw = nullptr;
-    if ((rc = buf.get(&d_sip, (size_t)N + 1)) || (rc = buf.get(&d_sdst, (size_t)E)) || (rc = buf.get(&d_sw, (size_t)E))) return rc;
-    ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E, "bad by-source CSR");
-    HIPCHK(hipMemcpy(d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
-    if (E) { HIPCHK(hipMemcpy(d_sdst, src_dst, sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(d_sw, src_w, sizeof(float) * E, hipMemcpyHostToDevice)); }
+    if ((rc = buf.get(&cx->d_sip, (size_t)N + 1)) || (rc = buf.get(&cx->d_sdst, (size_t)E)) || (rc = buf.get(&cx->d_sw, (size_t)E))) return rc;
+    ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E && (E == 0 || (src_dst && src_w)), "bad by-source CSR");
+    HIPCHK(hipMemcpy(cx->d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
+    if (E) { HIPCHK(hipMemcpy(cx->d_sdst, src_dst, sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(cx->d_sw, src_w, sizeof(float) * E, hipMemcpyHostToDevice)); }
 
     // template of the concat with the loop-invariant columns filled in (GNN.py:259, :263)
     float *tmpl = nullptr;
@@ -483,8 +535,7 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
         HIPCHK(hipMemcpy(d_masks_o, masks_output, mask_out_bytes, hipMemcpyHostToDevice));
     }
 
-    // ---- forward: while condition: state <- net_state(concat), training mode (GNN.py:271 with training=True) -----------
-    std::vector<NetCache> caches;
+    // ---- while condition: state <- net_state(concat), training mode (GNN.py:271 with training=True) ----------------------
     bool go = false;
     if ((rc = not_converged(state, nullptr, &go))) return rc;
     int k = 0;
@@ -494,26 +545,127 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
         HIPCHK(hipMemcpyAsync(inp, tmpl, sizeof(float) * (size_t)N * in_s, hipMemcpyDeviceToDevice, st));
         if (N) HIPCHK(hipMemcpy2DAsync(inp, sizeof(float) * in_s, state, sizeof(float) * Ds, sizeof(float) * Ds, (size_t)N, hipMemcpyDeviceToDevice, st));
         if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, state, Ds, Ds, inp + c_aggs, in_s, nullptr, 1))) return rc;
-        caches.emplace_back();
+        cx->caches.emplace_back();
         if ((rc = net_forward(st, buf, ns, N, inp, d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)k : nullptr, seed + 7919ull * (uint64_t)(k + 1),
-                              caches.back(), &y))) return rc;
+                              cx->caches.back(), &y))) return rc;
         std::swap(state, state_old);
         if (N) HIPCHK(hipMemcpyAsync(state, y, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
         ++k;
         if ((rc = not_converged(state, state_old, &go))) return rc;
     }
-    // ---- net_output on the masked rows, loss -------------------------------------------------------------------------------
-    float *feats = nullptr, *out_nodes = nullptr;
+    // ---- net_output on the masked rows --------------------------------------------------------------------------------------
+    float *feats = nullptr;
     if ((rc = buf.get(&feats, (size_t)M * wf))) return rc;
     if (M) {
         hipLaunchKernelGGL(k_gather_feats, cdiv(M * wf, 256), 256, 0, st, M, g->sh->masked_rows, state, Ds, g->nodes, g->NL, NLc, feats);
         HIPCHK(hipGetLastError());
     }
-    NetCache co;
-    if ((rc = net_forward(st, buf, no_, M, feats, d_masks_o, seed + 104729ull, co, &out_nodes))) return rc;
-    std::vector<float> h_out((size_t)M * T), h_dnodes((size_t)M * T, 0.0f), d_o;
-    if (M) HIPCHK(hipMemcpyAsync(h_out.data(), out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToHost, st));
+    if ((rc = net_forward(st, buf, no_, M, feats, d_masks_o, seed + 104729ull, cx->co, &cx->out_nodes))) return rc;
+    cx->state = state;
+    cx->k = k;
+    // publish the training-mode state / outputs as the loop's result: gnn_loop_get_state / get_output / readout and
+    // gnn_graph_update_labels (LGNN stacking) read them exactly like an inference run's
+    const int zero = 0;
+    if (N) HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+    if (M) HIPCHK(hipMemcpyAsync(l->out, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(l->kfinal_dev, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+    if (out_nodes_host && M) HIPCHK(hipMemcpyAsync(out_nodes_host, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    l->kfinal = 0;
+    *l->kfinal_host = 0;
+    l->ran = true;
+    *k_out = (float)k;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
+                                       float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host)
+{
+    ARGCHK(l && grads_state && grads_output, "bad arguments");
+    TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
+    if (!cx) return gnn_fail(GNN_ERR_STATE, "gnn_loop_train_forward has not been called");
+    gnn_graph *g = l->g;
+    const int64_t N = g->n_rows, M = g->n_masked;
+    const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->wf, NL = g->NL, k = cx->k;
+    ARGCHK(M == 0 || d_out_nodes, "d_out_nodes is NULL");
+    HIPCHK(hipSetDevice(l->device));
+    hipStream_t st = l->stream;
+    Buf &buf = cx->buf;
+    Net &ns = cx->ns, &no_ = cx->no_;
+    const int c_nodes = Ds, c_aggs = Ds + NLc, c_aggn = c_aggs + Ds;
+    int rc;
+    float *d_out = nullptr, *d_feats = nullptr, *d_state = nullptr, *tmp = nullptr, *d_nodes = nullptr, *via = nullptr;
+    if ((rc = buf.get(&d_out, (size_t)M * T)) || (rc = buf.get(&d_state, (size_t)N * Ds)) || (rc = buf.get(&tmp, (size_t)N * Ds))) return rc;
+    if (M) HIPCHK(hipMemcpyAsync(d_out, d_out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, st));
+    if ((rc = net_backward(st, buf, no_, cx->co, d_out, &d_feats))) return rc;
+    if (d_state_extra) { if (N) HIPCHK(hipMemcpyAsync(d_state, d_state_extra, sizeof(float) * (size_t)N * Ds, hipMemcpyHostToDevice, st)); }
+    else HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)N * Ds, st));
+    if (M) {
+        if (d_state_extra) {        // extra + scattered rows: scatter into a zero buffer, then add
+            HIPCHK(hipMemsetAsync(tmp, 0, sizeof(float) * (size_t)N * Ds, st));
+            hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, tmp);
+            hipLaunchKernelGGL(k_axpy1, cdiv(N * Ds, 256), 256, 0, st, N * Ds, tmp, d_state);
+        } else
+            hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, d_state);
+        HIPCHK(hipGetLastError());
+    }
+    const bool want_nodes = d_nodes_host != nullptr;
+    if (want_nodes && l->D) {
+        if ((rc = buf.get(&d_nodes, (size_t)N * NL)) || (rc = buf.get(&via, (size_t)N * NL))) return rc;
+        HIPCHK(hipMemsetAsync(d_nodes, 0, sizeof(float) * (size_t)N * NL, st));
+        if (M) {
+            hipLaunchKernelGGL(k_scatter_label_grad, cdiv(M * NL, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, NL, d_nodes);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    for (int it = k - 1; it >= 0; --it) {
+        float *d_inp = nullptr, *dy = nullptr;
+        if ((rc = buf.get(&dy, (size_t)N * Ds))) return rc;                       // net_backward overwrites its input
+        if (N) HIPCHK(hipMemcpyAsync(dy, d_state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+        if ((rc = net_backward(st, buf, ns, cx->caches[it], dy, &d_inp))) return rc;
+        // aggregated_states = Adjacency^T . state  =>  d state[src] = d inp[src, :Ds] + sum over arcs (src -> dst) of w * d agg[dst]
+        if ((rc = gnn_launch_spmm(st, N, cx->d_sip, cx->d_sdst, cx->d_sw, d_inp + c_aggs, Ds, in_s, tmp, Ds, nullptr, 1))) return rc;
+        if (N) {
+            hipLaunchKernelGGL(k_combine, cdiv(N * Ds, 256), 256, 0, st, N, Ds, d_inp, in_s, tmp, d_state);
+            HIPCHK(hipGetLastError());
+        }
+        if (want_nodes && l->D && N) {    // labels enter each body directly and through aggregated_nodes (GNN.py:228, :263)
+            if ((rc = gnn_launch_spmm(st, N, cx->d_sip, cx->d_sdst, cx->d_sw, d_inp + c_aggn, NL, in_s, via, NL, nullptr, 1))) return rc;
+            hipLaunchKernelGGL(k_nodes_grad, cdiv(N * NL, 256), 256, 0, st, N, NL, d_inp, in_s, c_nodes, via, d_nodes);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    HIPCHK(hipMemcpyAsync(grads_state, ns.grads, sizeof(float) * ns.g_total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(grads_output, no_.grads, sizeof(float) * no_.g_total, hipMemcpyDeviceToHost, st));
+    if (bn_batch_state && l->st->has_bn)
+        for (int it = 0; it < k; ++it)
+            HIPCHK(hipMemcpyAsync(bn_batch_state + (size_t)it * 2 * Ds, cx->caches[it].stats, sizeof(float) * 2 * Ds, hipMemcpyDeviceToHost, st));
+    if (bn_batch_output && l->ou->has_bn && M) HIPCHK(hipMemcpyAsync(bn_batch_output, cx->co.stats, sizeof(float) * 2 * T, hipMemcpyDeviceToHost, st));
+    if (want_nodes && N)        // D == 0: state_0 = nodes (GNN.py:265), so the gradient of the initial state IS the label gradient
+        HIPCHK(hipMemcpyAsync(d_nodes_host, l->D ? d_nodes : d_state, sizeof(float) * (size_t)N * NL, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    gnn_train_ctx_free(l);          // one backward per forward: the weight-gradient accumulators are spent
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
+                                   const float *targets, const float *sample_weights, int64_t n_targets, int loss_kind,
+                                   int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w,
+                                   const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
+                                   const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
+                                   float *loss_out, float *k_out, float *grads_state, float *grads_output,
+                                   float *bn_batch_state, float *bn_batch_output)
+{
+    ARGCHK(l && targets && sample_weights && loss_out && k_out && grads_state && grads_output, "bad arguments");
+    ARGCHK(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error");
+    const int64_t M = l->g->n_masked;
+    const int T = l->T;
+    ARGCHK(n_targets == (n_graphs > 0 ? n_graphs : M), "%lld target rows but %lld outputs", (long long)n_targets, (long long)(n_graphs > 0 ? n_graphs : M));
+    ARGCHK(n_graphs <= 0 || (ng_indptr && ng_node && ng_w), "NodeGraph^T CSR required for a graph-based step");
+    std::vector<float> h_out((size_t)M * T), h_dnodes((size_t)M * T, 0.0f), d_o;
+    int rc = gnn_loop_train_forward(l, src_indptr, src_dst, src_w, dropout_state, dropout_output, masks_state, masks_output, seed,
+                                    bn_state, bn_output, k_out, h_out.data());
+    if (rc) return rc;
     double loss = 0.0;
     if (n_graphs > 0) {                            // GNNgraphBased: out = NodeGraph^T . out_nodes (GNN.py:331-332)
         std::vector<float> og((size_t)n_graphs * T, 0.0f);
@@ -527,36 +679,8 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
     } else {
         loss_host(loss_kind, M, T, targets, h_out.data(), sample_weights, &loss, h_dnodes);
     }
-    // ---- backward ---------------------------------------------------------------------------------------------------------
-    float *d_out = nullptr, *d_feats = nullptr, *d_state = nullptr, *tmp = nullptr;
-    if ((rc = buf.get(&d_out, (size_t)M * T)) || (rc = buf.get(&d_state, (size_t)N * Ds)) || (rc = buf.get(&tmp, (size_t)N * Ds))) return rc;
-    if (M) HIPCHK(hipMemcpyAsync(d_out, h_dnodes.data(), sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, st));
-    if ((rc = net_backward(st, buf, no_, co, d_out, &d_feats))) return rc;
-    HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)N * Ds, st));
-    if (M) {
-        hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, d_state);
-        HIPCHK(hipGetLastError());
-    }
-    for (int it = k - 1; it >= 0; --it) {
-        float *d_inp = nullptr, *dy = nullptr;
-        if ((rc = buf.get(&dy, (size_t)N * Ds))) return rc;                       // net_backward overwrites its input
-        if (N) HIPCHK(hipMemcpyAsync(dy, d_state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
-        if ((rc = net_backward(st, buf, ns, caches[it], dy, &d_inp))) return rc;
-        // aggregated_states = Adjacency^T . state  =>  d state[src] = d inp[src, :Ds] + sum over arcs (src -> dst) of w * d agg[dst]
-        if ((rc = gnn_launch_spmm(st, N, d_sip, d_sdst, d_sw, d_inp + c_aggs, Ds, in_s, tmp, Ds, nullptr, 1))) return rc;
-        if (N) {
-            hipLaunchKernelGGL(k_combine, cdiv(N * Ds, 256), 256, 0, st, N, Ds, d_inp, in_s, tmp, d_state);
-            HIPCHK(hipGetLastError());
-        }
-    }
-    HIPCHK(hipMemcpyAsync(grads_state, ns.grads, sizeof(float) * ns.g_total, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(grads_output, no_.grads, sizeof(float) * no_.g_total, hipMemcpyDeviceToHost, st));
-    if (bn_batch_state && l->st->has_bn)
-        for (int it = 0; it < k; ++it)
-            HIPCHK(hipMemcpyAsync(bn_batch_state + (size_t)it * 2 * Ds, caches[it].stats, sizeof(float) * 2 * Ds, hipMemcpyDeviceToHost, st));
-    if (bn_batch_output && l->ou->has_bn && M) HIPCHK(hipMemcpyAsync(bn_batch_output, co.stats, sizeof(float) * 2 * T, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    rc = gnn_loop_train_backward(l, h_dnodes.data(), nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr);
+    if (rc) return rc;
     *loss_out = (float)loss;
-    *k_out = (float)k;
     return GNN_OK;
 }

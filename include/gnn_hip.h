@@ -136,6 +136,24 @@ int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *s
                         const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
                         float *loss_out, float *k_out, float *grads_state, float *grads_output,
                         float *bn_batch_state, float *bn_batch_output);
+/* The two halves of gnn_loop_train_step, for models whose loss spans several loops (LGNN 'parallel' / 'residual'
+ * training, reference GNN/LGNN.py:201-224 inside GNN_BaseClass.py:231-247, where layer i + 1's labels contain layer
+ * i's state / output, LGNN.py:227-260).
+ *   gnn_loop_train_forward   training-mode Loop; out_nodes [n_masked, T] (may be NULL) are the node-level outputs.  The
+ *                    training-mode state / outputs become the loop's result (gnn_loop_get_state / get_output / readout,
+ *                    gnn_graph_update_labels), and the context of the backward pass stays with the loop.
+ *   gnn_loop_train_backward  d_out_nodes [n_masked, T] = d loss / d out_nodes; d_state_extra [N, Ds] (or NULL) = an extra
+ *                    gradient on the final state; d_nodes [N, NL] (or NULL) receives d loss / d node labels.  One
+ *                    backward per forward.
+ *   gnn_loss_grad    host helper: *loss = sum_i w_i L(t_i, out_i) and d_out = d loss / d out (may be NULL). */
+int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
+                           const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
+                           const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
+                           float *k_out, float *out_nodes);
+int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
+                            float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes);
+int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets, const float *out,
+                  const float *sample_weights, double *loss, float *d_out);
 /* selects the implementation: 0 = unfused reference kernels (one kernel per TF op), 1 = fused gather+MLP kernel
  * when the shapes allow it (default), falling back to 0 otherwise.  *used (may be NULL) reports the choice. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);

@@ -120,13 +120,10 @@ def loss_forward_backward(kind, targets, out, weights, dtype=np.float64):
     return float(np.sum(loss * w)), do * w[:, None]
 
 
-def train_step(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
-               targets, sample_weights, loss='categorical_crossentropy', mean=True, graph_based=False, momentum=0.99,
-               dtype=np.float64):
-    """One training_step (GNN_BaseClass.py:231-247) without the optimizer.
-
-    masks_state: list (one per possible iteration) of {dense_index: mask [N, width]}; masks_output: {dense_index: mask [M, width]}.
-    Returns dict(k, loss, grads_state, grads_output, moving_state=(mean, var), moving_output=(mean, var), out)."""
+def train_forward(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
+                  momentum=0.99, dtype=np.float64):
+    """Training-mode Loop (GNN.py:251-280 with training=True): returns the context the backward pass needs, with the
+    node-level outputs ``out_nodes`` [M, T], the final ``state`` and the moving statistics after the k + 1 BN calls."""
     nodes = np.asarray(g['nodes'], dtype)
     n = nodes.shape[0]
     agg_arcs = orc.spmm_csr(g['arcT'], np.asarray(g['arcs'], dtype)[:, 2:], dtype)
@@ -136,7 +133,6 @@ def train_step(g, net_state, net_output, state_vect_dim, max_iteration, threshol
         agg_nodes = orc.spmm_csr(g['adjT'], nodes, dtype)
     else:
         state = nodes.copy()
-    ds = state.shape[1]
     state_old = np.ones_like(state)
     caches, k = [], 0
     n_st = len(net_state['activations'])
@@ -159,32 +155,133 @@ def train_step(g, net_state, net_output, state_vect_dim, max_iteration, threshol
         mov_o = [np.asarray(v, dtype).copy() for v in net_output['weights'][2 * n_ou + 2:2 * n_ou + 4]]
         mov_o[0] = mov_o[0] * momentum + cache_o['batch_mean'] * (1 - momentum)
         mov_o[1] = mov_o[1] * momentum + cache_o['batch_var'] * (1 - momentum)
-    out = out_nodes
-    if graph_based:
-        ng = np.asarray(g['NodeGraph'], dtype)
-        out = ng.T @ out_nodes
-    loss_value, d_out = loss_forward_backward(loss, targets, out, sample_weights, dtype)
-    if graph_based:
-        d_out = ng @ d_out
-    d_feats, grads_o = mlp_train_backward(d_out, net_output, cache_o, dtype)
+    return dict(g=g, net_state=net_state, net_output=net_output, D=state_vect_dim, k=k, caches=caches, cache_o=cache_o, mask=mask,
+                state=state, out_nodes=out_nodes, moving_state=mov_s, moving_output=mov_o, dtype=dtype)
+
+
+def train_backward(ctx, d_out_nodes, d_state_extra=None):
+    """Back-propagation through net_output and the k executed bodies.  d_out_nodes: d loss / d out_nodes [M, T];
+    d_state_extra: an additional gradient on the FINAL state [N, Ds] (LGNN: the next layer's labels contain it).
+    Returns (grads_state summed over the iterations, grads_output, d_nodes [N, NL]): d_nodes is the gradient with
+    respect to the node labels this layer saw (LGNN: they contain the previous layer's state / output)."""
+    g, dtype, k = ctx['g'], ctx['dtype'], ctx['k']
+    net_state, net_output, D = ctx['net_state'], ctx['net_output'], ctx['D']
+    nodes = np.asarray(g['nodes'], dtype)
+    n, nl = nodes.shape
+    ds = ctx['state'].shape[1]
+    mask = ctx['mask']
+    d_feats, grads_o = mlp_train_backward(d_out_nodes, net_output, ctx['cache_o'], dtype)
     d_state = np.zeros((n, ds), dtype)
     d_state[mask] = d_feats[:, :ds]
+    if d_state_extra is not None:
+        d_state = d_state + np.asarray(d_state_extra, dtype)
+    d_nodes = np.zeros((n, nl), dtype)
+    if D:
+        d_nodes[mask] += d_feats[:, ds:]
     grads_s = None
     indptr, src, w = g['adjT']
+    w = np.asarray(w, dtype)
     dst = np.repeat(np.arange(n), np.diff(indptr))
-    c_aggs = ds + (nodes.shape[1] if state_vect_dim else 0)
+    c_aggs = ds + (nl if D else 0)
+    c_aggn = c_aggs + ds
     for it in reversed(range(k)):
-        d_inp, gk = mlp_train_backward(d_state, net_state, caches[it], dtype)
+        d_inp, gk = mlp_train_backward(d_state, net_state, ctx['caches'][it], dtype)
         grads_s = gk if grads_s is None else [a + b for a, b in zip(grads_s, gk)]
         d_state = d_inp[:, :ds].copy()
         # aggregated_states = Adjacency^T . state  =>  d state[src] += w * d agg[dst]
-        np.add.at(d_state, src, np.asarray(w, dtype)[:, None] * d_inp[dst, c_aggs:c_aggs + ds])
+        np.add.at(d_state, src, w[:, None] * d_inp[dst, c_aggs:c_aggs + ds])
+        if D:       # node labels enter every iteration directly and through aggregated_nodes (GNN.py:228, :263)
+            d_nodes += d_inp[:, ds:ds + nl]
+            np.add.at(d_nodes, src, w[:, None] * d_inp[dst, c_aggn:c_aggn + nl])
+    if not D:
+        d_nodes = d_state           # state_0 = nodes (GNN.py:265)
     if grads_s is None:
+        n_st = len(net_state['activations'])
         grads_s = [np.zeros_like(np.asarray(v, dtype)) for v in net_state['weights'][:2 * n_st + (2 if net_state['batch_normalization'] else 0)]]
-    elif mean and k:
+    return grads_s, grads_o, d_nodes
+
+
+def train_step(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
+               targets, sample_weights, loss='categorical_crossentropy', mean=True, graph_based=False, momentum=0.99,
+               dtype=np.float64):
+    """One training_step (GNN_BaseClass.py:231-247) without the optimizer.
+
+    masks_state: list (one per possible iteration) of {dense_index: mask [N, width]}; masks_output: {dense_index: mask [M, width]}.
+    Returns dict(k, loss, grads_state, grads_output, moving_state=(mean, var), moving_output=(mean, var), out)."""
+    ctx = train_forward(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
+                        momentum, dtype)
+    out = ctx['out_nodes']
+    if graph_based:
+        ng = np.asarray(g['NodeGraph'], dtype)
+        out = ng.T @ out
+    loss_value, d_out = loss_forward_backward(loss, targets, out, sample_weights, dtype)
+    if graph_based:
+        d_out = ng @ d_out
+    grads_s, grads_o, _ = train_backward(ctx, d_out)
+    k = ctx['k']
+    if mean and k:
         grads_s = [gv / k for gv in grads_s]
-    return dict(k=float(k), loss=loss_value, grads_state=grads_s, grads_output=grads_o, moving_state=mov_s, moving_output=mov_o,
-                out=out, state=state)
+    return dict(k=float(k), loss=loss_value, grads_state=grads_s, grads_output=grads_o, moving_state=ctx['moving_state'],
+                moving_output=ctx['moving_output'], out=out, state=ctx['state'])
+
+
+def lgnn_train_step(g, layers, get_state, get_output, training_mode, state0, masks_state, masks_output, targets, sample_weights,
+                    loss='categorical_crossentropy', mean=True, graph_based=False, dtype=np.float64):
+    """Joint training step of an LGNN in 'parallel' or 'residual' mode (LGNN.py:201-224 inside GNN_BaseClass.py:231-247):
+    the tape spans the whole stack, so layer i also receives gradient through the labels of layer i + 1
+    (update_graph, LGNN.py:227-260: [nodes | state_i? | scatter(out_i)?]).
+
+    layers: list of dict(net_state, net_output, state_vect_dim, max_iteration, threshold); state0 / masks_*: one entry per layer.
+    Returns dict(k=[...], loss, grads_state=[...], grads_output=[...], outs=[...])."""
+    assert training_mode in ('parallel', 'residual')
+    L = len(layers)
+    nodes0 = np.asarray(g['nodes'], dtype)
+    nlb = nodes0.shape[1]
+    ctxs, outs = [], []
+    cur = g
+    ng = np.asarray(g['NodeGraph'], dtype) if graph_based else None
+    for i, ly in enumerate(layers):
+        ctx = train_forward(cur, ly['net_state'], ly['net_output'], ly['state_vect_dim'], ly['max_iteration'], ly['threshold'],
+                            state0[i], masks_state[i], masks_output[i], dtype=dtype)
+        ctxs.append(ctx)
+        outs.append(ng.T @ ctx['out_nodes'] if graph_based else ctx['out_nodes'])
+        if i < L - 1:
+            extra = []
+            if get_state: extra.append(ctx['state'])
+            if get_output:
+                sc = np.zeros((nodes0.shape[0], ctx['out_nodes'].shape[1]), dtype)
+                sc[ctx['mask']] = ctx['out_nodes']
+                extra.append(sc)
+            cur = dict(g)
+            cur['nodes'] = np.concatenate([nodes0] + extra, axis=1)
+    if training_mode == 'residual':
+        loss_value, d = loss_forward_backward(loss, targets, np.mean(outs, axis=0), sample_weights, dtype)
+        d_outs = [d / L] * L
+    else:
+        pairs = [loss_forward_backward(loss, targets, o, sample_weights, dtype) for o in outs]
+        loss_value = float(np.mean([p[0] for p in pairs]))
+        d_outs = [p[1] / L for p in pairs]
+    grads_s, grads_o = [None] * L, [None] * L
+    d_state_extra = d_out_extra = None
+    for i in reversed(range(L)):
+        ctx = ctxs[i]
+        d_nodes_out = ng @ d_outs[i] if graph_based else d_outs[i]
+        if d_out_extra is not None:
+            d_nodes_out = d_nodes_out + d_out_extra
+        gs, go, d_nodes = train_backward(ctx, d_nodes_out, d_state_extra)
+        if mean and ctx['k']:
+            gs = [v / ctx['k'] for v in gs]
+        grads_s[i], grads_o[i] = gs, go
+        if i > 0:
+            prev = ctxs[i - 1]
+            c = nlb
+            d_state_extra = d_out_extra = None
+            if get_state:
+                d_state_extra = d_nodes[:, c:c + prev['state'].shape[1]]
+                c += prev['state'].shape[1]
+            if get_output:
+                d_out_extra = d_nodes[prev['mask'], c:c + prev['out_nodes'].shape[1]]
+    return dict(k=[float(c['k']) for c in ctxs], loss=loss_value, grads_state=grads_s, grads_output=grads_o, outs=outs)
 
 
 def adam_update(params, grads, m, v, step, lr=0.001, beta1=0.9, beta2=0.999, eps=1e-7):

@@ -136,3 +136,114 @@ def test_train_loop_reduces_loss_and_keeps_history():
     lgnn = LGNN([model(GNNnodeBased, 0), model(GNNnodeBased, 1)], False, True, optimizers.Adam(0.02), losses.categorical_crossentropy, None, 'c')
     lgnn.train(gTr, 10, None, update_freq=5, training_mode='serial', verbose=0)
     assert lgnn.test(gVa)['Loss'] < before['Loss']
+
+
+@pytest.mark.parametrize('d,graph_based,get_state,get_output,mode,loss', [
+    (4, False, True, True, 'parallel', 'mean_squared_error'), (0, False, True, False, 'residual', 'categorical_crossentropy'),
+    (3, True, False, True, 'parallel', 'categorical_crossentropy'), (0, True, True, True, 'residual', 'mean_squared_error')])
+def test_lgnn_joint_training_step_matches_oracle(d, graph_based, get_state, get_output, mode, loss):
+    """LGNN 'parallel' / 'residual' training (reference LGNN.py:201-224, :343-344): gnn_loop_train_forward per layer with the
+    device relabelling in between, host loss, gnn_loop_train_backward per layer with the label gradients chained."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNnodeBased, GNNgraphBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import Sequential, Dense, Dropout, BatchNormalization
+    from GNN.graph_class import GraphObject, GraphTensor
+    rng = np.random.default_rng(40 + d)
+    n, nl, al, t, max_it, L = 300, 3, 2, 2, 3, 3
+    arcs = random_arcs(rng, n, 800, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    ng = None
+    if graph_based:
+        ng = np.zeros((n, 2), np.float32); ng[:180, 0] = 1 / 180; ng[180:, 1] = 1 / 120
+    set_mask = np.ones(n, bool) if graph_based else rng.random(n) < 0.8
+    g = orc.make_graph_dict(arcs, nodes, 'average', NodeGraph=ng)
+    g['set_mask'] = set_mask
+    m = int(set_mask.sum())
+    # GraphObject targets / sample_weights are per output_mask row (all nodes here); set_mask filters them (GNN_BaseClass.py:405-410)
+    n_full = 2 if graph_based else n
+    targets_full = np.eye(t)[rng.integers(0, t, n_full)].astype(np.float32)
+    weights_full = rng.uniform(0.5, 1.5, n_full).astype(np.float32)
+    targets, weights = (targets_full, weights_full) if graph_based else (targets_full[set_mask], weights_full[set_mask])
+
+    def sequential(net):
+        layers = []
+        nd = len(net['activations'])
+        for l in range(nd):
+            if net['dropout'].get(l): layers.append(Dropout(net['dropout'][l]))
+            layers.append(Dense(net['weights'][2 * l].shape[1], net['activations'][l], input_shape=(net['weights'][2 * l].shape[0],)))
+        if net['batch_normalization']: layers.append(BatchNormalization())
+        seq = Sequential(layers)
+        seq.set_weights([np.asarray(w, np.float32) for w in net['weights']])
+        return seq
+
+    layers, s0, ms, mo, gnns = [], [], [], [], []
+    nl_i = nl
+    for i in range(L):
+        ds, nlc = (d if d else nl_i), (nl_i if d else 0)
+        st = make_mlp(rng, al + 2 * (ds + nlc), [10, ds], 'tanh', gain=0.8, bn_random=True)
+        if loss == 'categorical_crossentropy':
+            ou = make_mlp(rng, ds + nlc, [t], 'tanh', out_activation='softmax')
+            ou.update(batch_normalization=False, weights=ou['weights'][:2])
+        else:
+            ou = make_mlp(rng, ds + nlc, [t], 'tanh', out_activation='softmax', bn_random=True)
+        st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1}
+        layers.append(dict(net_state=st, net_output=ou, state_vect_dim=d, max_iteration=max_it, threshold=0.0))
+        s0.append((0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None)
+        ms.append([{0: rng.random((n, st['weights'][0].shape[0])) > 0.2} for _ in range(max_it)])
+        mo.append({0: rng.random((m, ds + nlc)) > 0.1})
+        cls = GNNgraphBased if graph_based else GNNnodeBased
+        gnns.append(cls(net_state=sequential(st), net_output=sequential(ou), optimizer=None, loss_function=None, loss_arguments=None,
+                        state_vect_dim=d, max_iteration=max_it, threshold=0.0, addressed_problem='c'))
+        nl_i = nl + get_state * ds + get_output * t
+    ref = tro.lgnn_train_step(g, layers, get_state, get_output, mode, s0, ms, mo, targets, weights, loss=loss, mean=False, graph_based=graph_based)
+
+    loss_fn = losses.categorical_crossentropy if loss == 'categorical_crossentropy' else losses.mean_squared_error
+    lgnn = LGNN(gnns, get_state, get_output, optimizers.SGD(0.0), loss_fn, None, 'c')
+    lgnn.training_mode = mode
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=targets_full, set_mask=set_mask, sample_weights=weights_full, NodeGraph=ng,
+                     problem_based='g' if graph_based else 'n', aggregation_mode='average')
+    gt = GraphTensor.fromGraphObject(go)
+    res = lgnn.training_step(gt, mean=False, state0=s0,
+                             masks_state=[np.concatenate([mk[0].astype(np.uint8).ravel() for mk in msl]) for msl in ms],
+                             masks_output=[mol[0].astype(np.uint8).ravel() for mol in mo])
+    assert res['k'] == ref['k']
+    assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    for li in range(L):
+        np.testing.assert_allclose(res['outs'][li], ref['outs'][li], atol=2e-5)
+        for got, want in list(zip(res['grads_state'][li], ref['grads_state'][li])) + list(zip(res['grads_output'][li], ref['grads_output'][li])):
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want))), (li, got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)))
+
+
+def test_lgnn_parallel_training_reduces_loss():
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNnodeBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import MLP, set_seed
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(1)
+    set_seed(1)
+    graphs = []
+    for _ in range(5):
+        n = 100
+        nodes = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+        cls = (nodes[:, 0] - 0.5 * nodes[:, 2] > 0).astype(int)
+        graphs.append(GraphObject(arcs=random_arcs(rng, n, 300, 1), nodes=nodes, targets=np.eye(2)[cls]))
+
+    def model(layer):
+        w = 3 + 2 * (layer > 0)
+        st = MLP(1 + 2 * w, [8, w], 'tanh', 'glorot_normal', 'zeros', dropout_rate=0.1, dropout_pos=0)
+        ou = MLP(w, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
+        return GNNnodeBased(net_state=st, net_output=ou, optimizer=None, loss_function=losses.categorical_crossentropy, loss_arguments=None,
+                            state_vect_dim=0, max_iteration=3, threshold=0.01, addressed_problem='c')
+
+    for mode in ('parallel', 'residual'):
+        lgnn = LGNN([model(0), model(1), model(1)], False, True, optimizers.Adam(0.02), losses.categorical_crossentropy, None, 'c',
+                    extra_metrics={'Acc': lambda yt, yp: float(np.mean(yt == yp))})
+        before = lgnn.test(graphs[4])
+        lgnn.train(graphs[:4], 30, graphs[4], update_freq=10, max_fails=50, training_mode=mode, verbose=0)
+        after = lgnn.test(graphs[4])
+        assert after['Loss'] < 0.7 * before['Loss'] and after['Acc'] > 0.8, (mode, before, after)
+        with pytest.raises(ValueError):
+            lgnn.train(graphs[:4], 1, training_mode='serial', verbose=0)      # the mode of a model cannot change (reference LGNN.py:318-319)

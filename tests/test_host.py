@@ -144,8 +144,9 @@ def test_model_argument_errors_match_reference():
     with pytest.raises(NotImplementedError):
         GNNedgeBased.training_step(gnn, None, True)
     lg = LGNN([gnn], False, True, None, None, None, 'c')
-    with pytest.raises(NotImplementedError):
-        lg.train([], 1, training_mode='parallel')
+    lg.training_mode = 'parallel'
+    with pytest.raises(ValueError):
+        lg.train([], 1, training_mode='serial', verbose=0)        # reference LGNN.py:318-319
     assert st.dropout_rates() == [0.0, 0.0] and MLP(7, [5, 3], 'selu', 'zeros', 'zeros', dropout_rate=0.1, dropout_pos=[0, 1]).dropout_rates() == [0.1, 0.1, 0.0]
 
 

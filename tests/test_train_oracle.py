@@ -85,3 +85,67 @@ def test_training_forward_semantics():
     p, gr = [np.ones(3)], [np.array([0.5, -2.0, 1e-3])]
     new = tro.adam_update(p, gr, [np.zeros(3)], [np.zeros(3)], 1)
     np.testing.assert_allclose(new[0], 1 - 0.001 * np.sign(gr[0]), atol=5e-6)   # epsilon 1e-7 is not bias-corrected in Keras
+
+
+def _lgnn_case(rng, d, graph_based, get_state, get_output, n_layers=3, loss='mean_squared_error'):
+    n, nl, al, t = 30, 3, 2, 2
+    arcs = random_arcs(rng, n, 70, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    ng = None
+    if graph_based:
+        ng = np.zeros((n, 2), np.float32); ng[:18, 0] = 1 / 18; ng[18:, 1] = 1 / 12
+    g = orc.make_graph_dict(arcs, nodes, 'average', NodeGraph=ng)
+    if not graph_based:
+        g['set_mask'] = rng.random(n) < 0.8
+    m = int(np.sum(g['set_mask'] & g['output_mask']))
+    layers, s0, ms, mo = [], [], [], []
+    nl_i = nl
+    for i in range(n_layers):
+        ds, nlc = (d if d else nl_i), (nl_i if d else 0)
+        st = make_mlp(rng, al + 2 * (ds + nlc), [6, ds], 'tanh', gain=0.8, bn_random=True)
+        # categorical_crossentropy on a BatchNormalization output is clipped almost everywhere (zero gradient): no BN there
+        if loss == 'categorical_crossentropy':
+            ou = make_mlp(rng, ds + nlc, [t], 'tanh', out_activation='softmax')
+            ou.update(batch_normalization=False, weights=ou['weights'][:2])
+        else:
+            ou = make_mlp(rng, ds + nlc, [t], 'tanh', out_activation='softmax', bn_random=True)
+        st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1}
+        layers.append(dict(net_state=st, net_output=ou, state_vect_dim=d, max_iteration=3, threshold=0.0))
+        s0.append(0.1 * rng.standard_normal((n, ds)) if d else None)
+        ms.append([{0: rng.random((n, st['weights'][0].shape[0])) > 0.2} for _ in range(3)])
+        mo.append({0: rng.random((m, ds + nlc)) > 0.1})
+        nl_i = nl + get_state * ds + get_output * t
+    n_t = 2 if graph_based else m
+    targets = np.eye(t)[rng.integers(0, t, n_t)]
+    weights = rng.uniform(0.5, 1.5, n_t)
+    return g, layers, s0, ms, mo, targets, weights
+
+
+@pytest.mark.parametrize('d,graph_based,get_state,get_output,mode,loss', [
+    (3, False, True, True, 'parallel', 'mean_squared_error'), (0, False, True, False, 'residual', 'categorical_crossentropy'),
+    (2, True, False, True, 'parallel', 'categorical_crossentropy'), (0, True, True, True, 'residual', 'mean_squared_error')])
+def test_lgnn_joint_gradients_match_finite_differences(d, graph_based, get_state, get_output, mode, loss):
+    """'parallel' / 'residual' training: the gradient of layer i includes the path through layer i + 1's labels."""
+    rng = np.random.default_rng(11 + d)
+    g, layers, s0, ms, mo, targets, weights = _lgnn_case(rng, d, graph_based, get_state, get_output, loss=loss)
+    kw = dict(loss=loss, get_state=get_state, get_output=get_output, training_mode=mode, state0=s0, masks_state=ms, masks_output=mo,
+              targets=targets, sample_weights=weights, mean=False, graph_based=graph_based)
+    res = tro.lgnn_train_step(g, layers, **kw)
+    assert res['k'] == [3.0] * 3 and np.isfinite(res['loss'])
+    eps = 1e-6
+    for li, ly in enumerate(layers):
+        for net, grads in ((ly['net_state'], res['grads_state'][li]), (ly['net_output'], res['grads_output'][li])):
+            for wi in range(len(grads)):
+                w = net['weights'][wi] = np.asarray(net['weights'][wi], np.float64)
+                for _ in range(2):
+                    idx = tuple(rng.integers(0, s) for s in w.shape)
+                    old = w[idx]
+                    w[idx] = old + eps; lp = tro.lgnn_train_step(g, layers, **kw)['loss']
+                    w[idx] = old - eps; lm = tro.lgnn_train_step(g, layers, **kw)['loss']
+                    w[idx] = old
+                    fd = (lp - lm) / (2 * eps)
+                    assert abs(fd - grads[wi][idx]) <= 2e-5 * max(1.0, abs(fd)), (li, wi, idx, fd, grads[wi][idx])
+    # the first layer's gradient is NOT what it would get from its own loss alone (cross-layer path exists)
+    if mode == 'parallel':
+        own = tro.lgnn_train_step(g, layers[:1], **dict(kw, state0=s0[:1], masks_state=ms[:1], masks_output=mo[:1]))
+        assert not np.allclose(own['grads_state'][0][0] / 3, res['grads_state'][0][0], rtol=1e-3)
