@@ -130,6 +130,7 @@ class GNNnodeBased(BaseClass):
         if self._graph_based and not g.loop_mask().all():
             raise ValueError('graph-based GNN needs set_mask and output_mask all True')
         loop = self._device_loop(g.device_graph(self.device))
+        self._prepare_loop(g, loop)
         if self.state_vect_dim > 0:
             self.seed += 1
             loop.set_state0(state0, self.seed)
@@ -153,6 +154,9 @@ class GNNnodeBased(BaseClass):
         if loop.n_masked: self.net_output.update_moving_statistics(res['bn_batch_output'])
         return res
 
+    def _prepare_loop(self, g: GraphTensor, loop) -> None:
+        """Hook for subclasses that need more than the node mask on the device loop."""
+
     def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
         """(k, state [N, Ds], out [M, T]) with k a float as in the reference (GNN.py:267, :280)."""
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
@@ -171,16 +175,16 @@ class GNNedgeBased(GNNnodeBased):
             raise NotImplementedError('Loop(training=True) is not implemented on the MI355X engine yet')
         dev = g.device_graph(self.device)
         loop = self._device_loop(dev)
-        if not getattr(loop, '_edge_ready', False):
-            loop.set_edge_readout(*g.edge_readout_arrays())
-            loop._edge_ready = True
+        self._prepare_loop(g, loop)
         if self.state_vect_dim > 0:
             loop.set_state0(state0, self.seed)
         k = loop.run(False)
         return k, loop.state(), loop.output()
 
-    def training_step(self, g, mean: bool, **_):
-        raise NotImplementedError('GNNedgeBased.train(): the backward pass of the per-arc readout is not implemented on the MI355X engine yet')
+    def _prepare_loop(self, g: GraphTensor, loop) -> None:
+        if not getattr(loop, '_edge_ready', False):
+            loop.set_edge_readout(*g.edge_readout_arrays())
+            loop._edge_ready = True
 
 
 class GNNgraphBased(GNNnodeBased):

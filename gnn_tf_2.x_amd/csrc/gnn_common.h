@@ -173,6 +173,8 @@ int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const
 int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float *X, int64_t ldx, const float *W, const float *b,
                      int act, float *Y, int64_t ldy);
 int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base);
+// GNNedgeBased.apply_filters on `state` (training path): feats [n_edge_masked, 2 (Ds + NLc) + AL]
+int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state, float *feats);
 
 // gnn_train.hip
 void gnn_train_ctx_free(gnn_loop *l);

@@ -504,6 +504,17 @@ static int launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, c
     return GNN_OK;
 }
 
+int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state, float *feats)
+{
+    if (!l->n_edge_masked) return GNN_OK;
+    const gnn_graph *g = l->g;
+    const int64_t tot = l->n_edge_masked * l->ou->dims[0];
+    hipLaunchKernelGGL(k_feats_edge, cdiv(tot, 256), 256, 0, st, l->n_edge_masked, l->edge_rows, l->edge_dst, g->sh->adj_src, state, state,
+                       l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, l->edge_labels, g->AL, feats);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
 int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base)
 {
     return launch_check(st, n_rows, d, s, so, thr, flag_rank_base, nullptr, 1);

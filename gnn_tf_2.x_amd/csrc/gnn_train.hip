@@ -426,6 +426,23 @@ __global__ void k_scatter_label_grad(int64_t m, const int32_t *rows, const float
     d_nodes[(int64_t)rows[q] * NL + c] += d_feats[q * wf + Ds + c];
 }
 
+// GNNedgeBased backward: row q of d_feats = d [F[dst(e)] | F[src(e)] | arc label], e = rows[q]; F = [state | labels?].
+// Both endpoints receive their half (several arcs share a node: atomics); the arc-label columns are data.
+__global__ void k_scatter_edge_grad(int64_t m, const int32_t *rows, const int32_t *entry_dst, const int32_t *adj_src, const float *d_feats,
+                                    int we, int wn, int Ds, int NL, float *d_state, float *d_nodes)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * 2 * wn) return;
+    const int64_t q = t / (2 * wn);
+    int c = (int)(t - q * 2 * wn);
+    const int64_t e = rows[q];
+    const float v = d_feats[q * we + c];
+    const int64_t node = c < wn ? entry_dst[e] : adj_src[e];
+    if (c >= wn) c -= wn;
+    if (c < Ds) atomicAdd(d_state + node * Ds + c, v);
+    else if (d_nodes) atomicAdd(d_nodes + node * NL + (c - Ds), v);
+}
+
 __global__ void k_axpy1(int64_t n, const float *x, float *y)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,13 +488,14 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
                                       float *k_out, float *out_nodes_host)
 {
     ARGCHK(l && src_indptr && dropout_state && dropout_output && k_out, "bad arguments");
-    ARGCHK(l->world == 1 && !l->edge_mode && !l->edge_expected, "training is single-GPU, node/graph-based only");
+    ARGCHK(l->world == 1, "training is single-GPU");
+    ARGCHK(l->edge_mode == l->edge_expected, "edge-based net_output: call gnn_loop_set_edge_readout first");
     ARGCHK(!l->st->has_bn || bn_state, "net_state ends with BatchNormalization: gamma|beta required");
     ARGCHK(!l->ou->has_bn || bn_output, "net_output ends with BatchNormalization: gamma|beta required");
     if (!l->have_state0 && l->D) return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
     gnn_graph *g = l->g;
-    const int64_t N = g->n_rows, M = g->n_masked, E = g->E;
-    const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->wf;
+    const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked, E = g->E;
+    const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->ou->dims[0];
     HIPCHK(hipSetDevice(l->device));
     hipStream_t st = l->stream;
     gnn_train_ctx_free(l);
@@ -556,7 +574,9 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     // ---- net_output on the masked rows --------------------------------------------------------------------------------------
     float *feats = nullptr;
     if ((rc = buf.get(&feats, (size_t)M * wf))) return rc;
-    if (M) {
+    if (l->edge_mode) {
+        if ((rc = gnn_launch_feats_edge(st, l, state, feats))) return rc;
+    } else if (M) {
         hipLaunchKernelGGL(k_gather_feats, cdiv(M * wf, 256), 256, 0, st, M, g->sh->masked_rows, state, Ds, g->nodes, g->NL, NLc, feats);
         HIPCHK(hipGetLastError());
     }
@@ -585,8 +605,8 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
     TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
     if (!cx) return gnn_fail(GNN_ERR_STATE, "gnn_loop_train_forward has not been called");
     gnn_graph *g = l->g;
-    const int64_t N = g->n_rows, M = g->n_masked;
-    const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->wf, NL = g->NL, k = cx->k;
+    const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked;
+    const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->ou->dims[0], NL = g->NL, k = cx->k;
     ARGCHK(M == 0 || d_out_nodes, "d_out_nodes is NULL");
     HIPCHK(hipSetDevice(l->device));
     hipStream_t st = l->stream;
@@ -600,7 +620,19 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
     if ((rc = net_backward(st, buf, no_, cx->co, d_out, &d_feats))) return rc;
     if (d_state_extra) { if (N) HIPCHK(hipMemcpyAsync(d_state, d_state_extra, sizeof(float) * (size_t)N * Ds, hipMemcpyHostToDevice, st)); }
     else HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)N * Ds, st));
-    if (M) {
+    const bool want_nodes = d_nodes_host != nullptr;
+    if (want_nodes && l->D) {
+        if ((rc = buf.get(&d_nodes, (size_t)N * NL)) || (rc = buf.get(&via, (size_t)N * NL))) return rc;
+        HIPCHK(hipMemsetAsync(d_nodes, 0, sizeof(float) * (size_t)N * NL, st));
+    }
+    if (l->edge_mode) {
+        if (M) {
+            const int wn = Ds + NLc;
+            hipLaunchKernelGGL(k_scatter_edge_grad, cdiv(M * 2 * wn, 256), 256, 0, st, M, l->edge_rows, l->edge_dst, g->sh->adj_src, d_feats, wf, wn,
+                               Ds, NL, d_state, d_nodes);
+            HIPCHK(hipGetLastError());
+        }
+    } else if (M) {
         if (d_state_extra) {        // extra + scattered rows: scatter into a zero buffer, then add
             HIPCHK(hipMemsetAsync(tmp, 0, sizeof(float) * (size_t)N * Ds, st));
             hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, tmp);
@@ -609,10 +641,7 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
             hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, d_state);
         HIPCHK(hipGetLastError());
     }
-    const bool want_nodes = d_nodes_host != nullptr;
-    if (want_nodes && l->D) {
-        if ((rc = buf.get(&d_nodes, (size_t)N * NL)) || (rc = buf.get(&via, (size_t)N * NL))) return rc;
-        HIPCHK(hipMemsetAsync(d_nodes, 0, sizeof(float) * (size_t)N * NL, st));
+    if (d_nodes && !l->edge_mode) {
         if (M) {
             hipLaunchKernelGGL(k_scatter_label_grad, cdiv(M * NL, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, NL, d_nodes);
             HIPCHK(hipGetLastError());
@@ -658,8 +687,9 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
 {
     ARGCHK(l && targets && sample_weights && loss_out && k_out && grads_state && grads_output, "bad arguments");
     ARGCHK(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error");
-    const int64_t M = l->g->n_masked;
+    const int64_t M = l->edge_mode ? l->n_edge_masked : l->g->n_masked;
     const int T = l->T;
+    ARGCHK(!(l->edge_mode && n_graphs > 0), "an edge-based loop has no graph readout");
     ARGCHK(n_targets == (n_graphs > 0 ? n_graphs : M), "%lld target rows but %lld outputs", (long long)n_targets, (long long)(n_graphs > 0 ? n_graphs : M));
     ARGCHK(n_graphs <= 0 || (ng_indptr && ng_node && ng_w), "NodeGraph^T CSR required for a graph-based step");
     std::vector<float> h_out((size_t)M * T), h_dnodes((size_t)M * T, 0.0f), d_o;

@@ -121,7 +121,7 @@ def loss_forward_backward(kind, targets, out, weights, dtype=np.float64):
 
 
 def train_forward(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
-                  momentum=0.99, dtype=np.float64):
+                  momentum=0.99, dtype=np.float64, edge_based=False):
     """Training-mode Loop (GNN.py:251-280 with training=True): returns the context the backward pass needs, with the
     node-level outputs ``out_nodes`` [M, T], the final ``state`` and the moving statistics after the k + 1 BN calls."""
     nodes = np.asarray(g['nodes'], dtype)
@@ -148,7 +148,9 @@ def train_forward(g, net_state, net_output, state_vect_dim, max_iteration, thres
         k, state, state_old = k + 1, new, state
     mask = np.logical_and(g['set_mask'], g['output_mask'])
     feats = state if not state_vect_dim else np.concatenate([state, nodes], axis=1)
-    out_nodes, cache_o = mlp_train_forward(feats[mask], net_output, masks_output, dtype)
+    # GNNedgeBased.apply_filters (GNN.py:289-302): one row per masked arc, [F[dst] | F[src] | arc label]
+    rows_in = orc.edge_features(g, state, state_vect_dim, dtype) if edge_based else feats[mask]
+    out_nodes, cache_o = mlp_train_forward(rows_in, net_output, masks_output, dtype)
     n_ou = len(net_output['activations'])
     mov_o = None
     if net_output['batch_normalization']:
@@ -156,7 +158,7 @@ def train_forward(g, net_state, net_output, state_vect_dim, max_iteration, thres
         mov_o[0] = mov_o[0] * momentum + cache_o['batch_mean'] * (1 - momentum)
         mov_o[1] = mov_o[1] * momentum + cache_o['batch_var'] * (1 - momentum)
     return dict(g=g, net_state=net_state, net_output=net_output, D=state_vect_dim, k=k, caches=caches, cache_o=cache_o, mask=mask,
-                state=state, out_nodes=out_nodes, moving_state=mov_s, moving_output=mov_o, dtype=dtype)
+                state=state, out_nodes=out_nodes, moving_state=mov_s, moving_output=mov_o, dtype=dtype, edge_based=edge_based)
 
 
 def train_backward(ctx, d_out_nodes, d_state_extra=None):
@@ -172,16 +174,24 @@ def train_backward(ctx, d_out_nodes, d_state_extra=None):
     mask = ctx['mask']
     d_feats, grads_o = mlp_train_backward(d_out_nodes, net_output, ctx['cache_o'], dtype)
     d_state = np.zeros((n, ds), dtype)
-    d_state[mask] = d_feats[:, :ds]
-    if d_state_extra is not None:
-        d_state = d_state + np.asarray(d_state_extra, dtype)
     d_nodes = np.zeros((n, nl), dtype)
-    if D:
-        d_nodes[mask] += d_feats[:, ds:]
-    grads_s = None
     indptr, src, w = g['adjT']
     w = np.asarray(w, dtype)
     dst = np.repeat(np.arange(n), np.diff(indptr))
+    if ctx.get('edge_based'):       # mask is over arcs; both endpoints of a masked arc receive gradient
+        wn = ds + (nl if D else 0)
+        np.add.at(d_state, dst[mask], d_feats[:, :ds])
+        np.add.at(d_state, src[mask], d_feats[:, wn:wn + ds])
+        if D:
+            np.add.at(d_nodes, dst[mask], d_feats[:, ds:wn])
+            np.add.at(d_nodes, src[mask], d_feats[:, wn + ds:2 * wn])
+    else:
+        d_state[mask] = d_feats[:, :ds]
+        if D:
+            d_nodes[mask] += d_feats[:, ds:]
+    if d_state_extra is not None:
+        d_state = d_state + np.asarray(d_state_extra, dtype)
+    grads_s = None
     c_aggs = ds + (nl if D else 0)
     c_aggn = c_aggs + ds
     for it in reversed(range(k)):
@@ -203,13 +213,13 @@ def train_backward(ctx, d_out_nodes, d_state_extra=None):
 
 def train_step(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
                targets, sample_weights, loss='categorical_crossentropy', mean=True, graph_based=False, momentum=0.99,
-               dtype=np.float64):
+               dtype=np.float64, edge_based=False):
     """One training_step (GNN_BaseClass.py:231-247) without the optimizer.
 
     masks_state: list (one per possible iteration) of {dense_index: mask [N, width]}; masks_output: {dense_index: mask [M, width]}.
     Returns dict(k, loss, grads_state, grads_output, moving_state=(mean, var), moving_output=(mean, var), out)."""
     ctx = train_forward(g, net_state, net_output, state_vect_dim, max_iteration, threshold, state0, masks_state, masks_output,
-                        momentum, dtype)
+                        momentum, dtype, edge_based)
     out = ctx['out_nodes']
     if graph_based:
         ng = np.asarray(g['NodeGraph'], dtype)

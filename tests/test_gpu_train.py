@@ -247,3 +247,65 @@ def test_lgnn_parallel_training_reduces_loss():
         assert after['Loss'] < 0.7 * before['Loss'] and after['Acc'] > 0.8, (mode, before, after)
         with pytest.raises(ValueError):
             lgnn.train(graphs[:4], 1, training_mode='serial', verbose=0)      # the mode of a model cannot change (reference LGNN.py:318-319)
+
+
+@pytest.mark.parametrize('d', [4, 0])
+def test_edge_based_training_step_matches_oracle(d):
+    """GNNedgeBased training (reference GNN.py:289-302 under GNN_BaseClass.py:231-247): per-arc readout in training mode and
+    its backward pass (both endpoints of every masked arc receive gradient), through GNNedgeBased.training_step."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNedgeBased
+    from GNN.MLP import Sequential, Dense, Dropout, BatchNormalization
+    from GNN.graph_class import GraphObject, GraphTensor
+    rng = np.random.default_rng(60 + d)
+    n, nl, al, max_it = 200, 3, 2, 4
+    arcs = random_arcs(rng, n, 600, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    e = len(arcs)
+    set_mask = rng.random(e) < 0.75
+    targets_full = np.eye(2)[rng.integers(0, 2, e)].astype(np.float32)
+    weights_full = rng.uniform(0.5, 1.5, e).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    g['set_mask'], g['output_mask'] = set_mask, np.ones(e, bool)
+    m = int(set_mask.sum())
+    ds, nlc = (d if d else nl), (nl if d else 0)
+    st = make_mlp(rng, al + 2 * (ds + nlc), [12, ds], 'tanh', gain=0.8, bn_random=True)
+    ou = make_mlp(rng, 2 * (ds + nlc) + al, [7, 2], 'tanh', out_activation='softmax')
+    ou.update(batch_normalization=False, weights=ou['weights'][:4])
+    st['dropout'], ou['dropout'] = {0: 0.2}, {1: 0.3}
+    ms = [{0: rng.random((n, st['weights'][0].shape[0])) > 0.2} for _ in range(max_it)]
+    mo = {1: rng.random((m, 7)) > 0.3}
+    s0 = (0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None
+    ref = tro.train_step(g, st, ou, d, max_it, 0.0, s0, ms, mo, targets_full[set_mask], weights_full[set_mask], mean=False, edge_based=True)
+
+    def sequential(net):
+        layers = []
+        for l in range(len(net['activations'])):
+            if net['dropout'].get(l): layers.append(Dropout(net['dropout'][l]))
+            layers.append(Dense(net['weights'][2 * l].shape[1], net['activations'][l], input_shape=(net['weights'][2 * l].shape[0],)))
+        if net['batch_normalization']: layers.append(BatchNormalization())
+        seq = Sequential(layers)
+        seq.set_weights([np.asarray(w, np.float32) for w in net['weights']])
+        return seq
+
+    gnn = GNNedgeBased(net_state=sequential(st), net_output=sequential(ou), optimizer=optimizers.SGD(0.0),
+                       loss_function=losses.categorical_crossentropy, loss_arguments=None, state_vect_dim=d, max_iteration=max_it,
+                       threshold=0.0, addressed_problem='c')
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=targets_full, set_mask=set_mask, sample_weights=weights_full, problem_based='a',
+                     aggregation_mode='average')
+    res = gnn.training_step(GraphTensor.fromGraphObject(go), mean=False, state0=s0,
+                            masks_state=np.concatenate([mk[0].astype(np.uint8).ravel() for mk in ms]), masks_output=mo[1].astype(np.uint8).ravel())
+    assert res['k'] == ref['k'] == max_it
+    assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    for got, want in list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output'])):
+        assert got.shape == want.shape
+        assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want))), (got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)))
+    # and a few Adam steps reduce the loss of a learnable arc task (label = sign of the first arc label)
+    cls = (arcs[:, 2] > np.median(arcs[:, 2])).astype(int)
+    go2 = GraphObject(arcs=arcs, nodes=nodes, targets=np.eye(2)[cls], problem_based='a', aggregation_mode='average')
+    gnn2 = GNNedgeBased(net_state=sequential(dict(st, dropout={})), net_output=sequential(dict(ou, dropout={})), optimizer=optimizers.Adam(0.02),
+                        loss_function=losses.categorical_crossentropy, loss_arguments=None, state_vect_dim=d, max_iteration=max_it,
+                        threshold=0.01, addressed_problem='c')
+    before = gnn2.test(go2)['Loss']
+    gnn2.train(go2, 25, None, update_freq=25, verbose=0)
+    assert gnn2.test(go2)['Loss'] < 0.7 * before

@@ -140,9 +140,6 @@ def test_model_argument_errors_match_reference():
     assert BaseClass.checktype(None) is None
     gnn = mk()
     assert gnn.get_weights()[0][0][0].shape == (7, 3)
-    from GNN.GNN import GNNedgeBased
-    with pytest.raises(NotImplementedError):
-        GNNedgeBased.training_step(gnn, None, True)
     lg = LGNN([gnn], False, True, None, None, None, 'c')
     lg.training_mode = 'parallel'
     with pytest.raises(ValueError):

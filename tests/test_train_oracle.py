@@ -149,3 +149,44 @@ def test_lgnn_joint_gradients_match_finite_differences(d, graph_based, get_state
     if mode == 'parallel':
         own = tro.lgnn_train_step(g, layers[:1], **dict(kw, state0=s0[:1], masks_state=ms[:1], masks_output=mo[:1]))
         assert not np.allclose(own['grads_state'][0][0] / 3, res['grads_state'][0][0], rtol=1e-3)
+
+
+@pytest.mark.parametrize('d', [3, 0])
+def test_edge_based_gradients_match_finite_differences(d):
+    """GNNedgeBased: net_output runs on [F[dst] | F[src] | arc label] of the masked arcs (GNN.py:289-302); both endpoints of
+    every masked arc receive gradient."""
+    rng = np.random.default_rng(21 + d)
+    n, nl, al, e = 30, 3, 2, 80
+    arcs = random_arcs(rng, n, e, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    e = len(g['arcs'])
+    g['set_mask'] = rng.random(e) < 0.7
+    g['output_mask'] = np.ones(e, bool)
+    ds, nlc = (d if d else nl), (nl if d else 0)
+    st = make_mlp(rng, al + 2 * (ds + nlc), [6, ds], 'tanh', gain=0.8, bn_random=True)
+    ou = make_mlp(rng, 2 * (ds + nlc) + al, [5, 2], 'tanh', out_activation='softmax')
+    ou.update(batch_normalization=False, weights=ou['weights'][:4])
+    st['dropout'], ou['dropout'] = {0: 0.2}, {1: 0.3}
+    m = int(g['set_mask'].sum())
+    ms = [{0: rng.random((n, st['weights'][0].shape[0])) > 0.2} for _ in range(3)]
+    mo = {1: rng.random((m, 5)) > 0.3}
+    targets = np.eye(2)[rng.integers(0, 2, m)]
+    weights = rng.uniform(0.5, 1.5, m)
+    s0 = 0.1 * rng.standard_normal((n, ds)) if d else None
+    kw = dict(state_vect_dim=d, max_iteration=3, threshold=0.0, state0=s0, masks_state=ms, masks_output=mo, targets=targets,
+              sample_weights=weights, mean=False, edge_based=True)
+    res = tro.train_step(g, st, ou, **kw)
+    assert res['k'] == 3 and res['out'].shape == (m, 2)
+    eps = 1e-6
+    for net, grads in ((st, res['grads_state']), (ou, res['grads_output'])):
+        for wi in range(len(grads)):
+            w = net['weights'][wi] = np.asarray(net['weights'][wi], np.float64)
+            for _ in range(3):
+                idx = tuple(rng.integers(0, s_) for s_ in w.shape)
+                old = w[idx]
+                w[idx] = old + eps; lp = tro.train_step(g, st, ou, **kw)['loss']
+                w[idx] = old - eps; lm = tro.train_step(g, st, ou, **kw)['loss']
+                w[idx] = old
+                fd = (lp - lm) / (2 * eps)
+                assert abs(fd - grads[wi][idx]) <= 1e-5 * max(1.0, abs(fd)), (wi, idx, fd, grads[wi][idx])
