@@ -136,10 +136,8 @@ class GNNnodeBased(BaseClass):
             loop.set_state0(state0, self.seed)
         targets = self.get_filtered_tensor(g, g.targets)
         weights = self.get_filtered_tensor(g, g.sample_weights)
-        if not hasattr(g, '_by_source'):
-            g._by_source = g.adjacency_by_source()
         self._train_calls = getattr(self, '_train_calls', 0) + 1
-        res = loop.train_step(self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device), g._by_source, targets, weights,
+        res = loop.train_step(self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device), None, targets, weights,
                               kind, g.nodegraph_csr() if self._graph_based else None, dropout_state=self.net_state.dropout_rates(),
                               dropout_output=self.net_output.dropout_rates(), masks_state=masks_state, masks_output=masks_output,
                               seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),

@@ -195,8 +195,6 @@ class LGNN(BaseClass):
         masks_output = masks_output or [None] * L
         targets = self.GNNS_TYPE.get_filtered_tensor(g, g.targets)
         weights = self.GNNS_TYPE.get_filtered_tensor(g, g.sample_weights)
-        if not hasattr(g, '_by_source'):
-            g._by_source = g.adjacency_by_source()
         base = g.device_graph(self.gnns[0].device)
         derived = g.__dict__.setdefault('_lgnn_graphs', {})
         mask = g.loop_mask()
@@ -209,7 +207,7 @@ class LGNN(BaseClass):
                 gnn.seed += 1
                 loop.set_state0(state0[idx], gnn.seed)
             gnn._train_calls = getattr(gnn, '_train_calls', 0) + 1
-            k, out_nodes = loop.train_forward(gnn.net_state.device_mlp(gnn.device), gnn.net_output.device_mlp(gnn.device), g._by_source,
+            k, out_nodes = loop.train_forward(gnn.net_state.device_mlp(gnn.device), gnn.net_output.device_mlp(gnn.device), None,
                                               dropout_state=gnn.net_state.dropout_rates(), dropout_output=gnn.net_output.dropout_rates(),
                                               masks_state=masks_state[idx], masks_output=masks_output[idx],
                                               seed=gnn.seed * 1000003 + gnn._train_calls, bn_state=gnn.net_state.bn_gamma_beta(),

@@ -289,7 +289,7 @@ class Loop:
                    bn_state=None, bn_output=None, max_iter: int = 0):
         """gnn_loop_train_step: loss, iteration count, raw gradients (lists shaped like the trainable arrays) and the
         BatchNormalization batch statistics of every call."""
-        sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2]))
+        sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2])) if src_csr is not None else (None, None, None)
         targets, sample_weights = _f32(targets), _f32(sample_weights)
         ls, lo = net_state.n, net_output.n
         ds_ = _f32(dropout_state if dropout_state is not None else np.zeros(ls + 1))
@@ -351,7 +351,7 @@ class Loop:
                       masks_state=None, masks_output=None, seed: int = 0, bn_state=None, bn_output=None):
         """gnn_loop_train_forward: training-mode Loop; returns (k, node-level outputs [n_masked, T]).  The loop's state() /
         output() / readout() then hold the training-mode results, and train_backward() may be called once."""
-        sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2]))
+        sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2])) if src_csr is not None else (None, None, None)
         ds_ = _f32(dropout_state if dropout_state is not None else np.zeros(net_state.n + 1))
         do_ = _f32(dropout_output if dropout_output is not None else np.zeros(net_output.n + 1))
         ms = np.ascontiguousarray(masks_state, np.uint8) if masks_state is not None else None

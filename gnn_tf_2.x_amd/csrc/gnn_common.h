@@ -95,6 +95,10 @@ struct gnn_graph_shared {
     float *adj_w = nullptr, *arc_w = nullptr, *arc_labels = nullptr;
     uint8_t *mask = nullptr;
     int max_degree = 0;
+    // Adjacency as CSR over SOURCE nodes (destinations ascending): operand of the transposed aggregation of the backward
+    // pass; built on first use by gnn_train.hip when the caller passes no by-source arrays
+    int32_t *src_indptr = nullptr, *src_dst = nullptr;
+    float *src_w = nullptr;
 };
 
 struct gnn_graph {
@@ -164,6 +168,7 @@ struct gnn_loop {
     float total_ms = 0.f, avg_iter_ms = 0.f;
     int n_iter_timed = 0;
     void *train_ctx = nullptr;              // gnn_train.hip: what train_forward leaves for train_backward
+    void *train_arena = nullptr;            // gnn_train.hip: device scratch slabs kept from step to step
 };
 
 // gnn_engine.hip
@@ -178,6 +183,7 @@ int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state,
 
 // gnn_train.hip
 void gnn_train_ctx_free(gnn_loop *l);
+void gnn_train_arena_free(gnn_loop *l);
 
 // gnn_fused.hip
 bool gnn_fused_supported(const gnn_loop *l);

@@ -559,6 +559,7 @@ static void graph_release_shared(gnn_graph_shared *sh)
     if (!sh || --sh->refs > 0) return;
     (void)hipFree(sh->indptr); (void)hipFree(sh->adj_src); (void)hipFree(sh->masked_rows);
     (void)hipFree(sh->adj_w); (void)hipFree(sh->arc_w); (void)hipFree(sh->arc_labels); (void)hipFree(sh->mask);
+    (void)hipFree(sh->src_indptr); (void)hipFree(sh->src_dst); (void)hipFree(sh->src_w);
     delete sh;
 }
 
@@ -1268,6 +1269,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     if (!l) return GNN_OK;
     (void)hipSetDevice(l->device);
     gnn_train_ctx_free(l);
+    gnn_train_arena_free(l);
     for (int b = 0; b < 2; ++b) { (void)hipFree(l->state[b]); (void)hipFree(l->tmp[b]); (void)hipFree(l->otmp[b]); }
     (void)hipFree(l->inp); (void)hipFree(l->inv); (void)hipFree(l->state_init); (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->flags); (void)hipFree(l->kfinal_dev); (void)hipFree(l->tile_ctr);
     if (l->kfinal_host) (void)hipHostFree(l->kfinal_host);

@@ -20,6 +20,14 @@ namespace {
 
 inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// rows handled by one block of the column reductions / weight-gradient tiles: about 64 blocks along the rows, so that small
+// batches (a few hundred rows) still spread over the chip; a multiple of 16 (k_wgrad's row tile), at most 1024
+inline int64_t rows_per_block(int64_t n)
+{
+    const int64_t r = ((n + 63) / 64 + 15) / 16 * 16;
+    return std::min<int64_t>(1024, std::max<int64_t>(32, r));
+}
+
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
     x += 0x9E3779B97F4A7C15ull;
@@ -197,18 +205,50 @@ __global__ void k_combine(int64_t n, int Ds, const float *d_inp, int in_s, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-struct Buf {                      // device scratch, freed at the end of the step
-    std::vector<void *> all;
+// Device scratch of the training step: a bump allocator over slabs that stay with the loop from step to step (a step makes
+// a few hundred allocations; hipMalloc / hipFree for each of them dominated the step time).  reset() at the next forward.
+struct TrainArena {
+    struct Slab { char *p; size_t size; };
+    std::vector<Slab> slabs;
+    size_t cur = 0, off = 0;
+    void reset() { cur = 0; off = 0; }
+    void *alloc(size_t bytes)
+    {
+        bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+        for (; cur < slabs.size(); ++cur, off = 0)
+            if (off + bytes <= slabs[cur].size) {
+                void *r = slabs[cur].p + off;
+                off += bytes;
+                return r;
+            }
+        Slab s{nullptr, std::max<size_t>(bytes, (size_t)32 << 20)};
+        if (hipMalloc((void **)&s.p, s.size) != hipSuccess) return nullptr;
+        slabs.push_back(s);
+        cur = slabs.size() - 1;
+        off = bytes;
+        return s.p;
+    }
+    ~TrainArena() { for (Slab &s : slabs) (void)hipFree(s.p); }
+};
+
+struct Buf {                      // typed front end of the arena
+    TrainArena *arena = nullptr;
     template <typename T>
     int get(T **p, size_t count)
     {
-        *p = nullptr;
-        if (hipMalloc((void **)p, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
-        all.push_back(*p);
+        *p = static_cast<T *>(arena->alloc(count * sizeof(T)));
+        if (!*p) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
         return GNN_OK;
     }
-    ~Buf() { for (void *p : all) (void)hipFree(p); }
 };
+
+__global__ void k_transpose(int ni, int no, const float *W, float *WT)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ni * no) return;
+    const int i = t / no, j = t - i * no;
+    WT[(size_t)j * ni + i] = W[t];
+}
 
 struct NetCache {                 // what one training-mode forward of a Sequential leaves for the backward pass
     std::vector<float *> hin, z, a;
@@ -227,7 +267,7 @@ struct Net {
     size_t g_total = 0;
 };
 
-int net_setup(Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host)
+int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host)
 {
     net.m = m;
     const int L = m->n_layers;
@@ -236,13 +276,10 @@ int net_setup(Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const fl
     size_t off = 0;
     for (int l = 0; l < L; ++l) {
         const int ni = m->dims[l], no = m->dims[l + 1];
-        std::vector<float> W((size_t)ni * no), WT((size_t)ni * no);
-        HIPCHK(hipMemcpy(W.data(), m->W[l], W.size() * sizeof(float), hipMemcpyDeviceToHost));
-        for (int i = 0; i < ni; ++i)
-            for (int j = 0; j < no; ++j) WT[(size_t)j * ni + i] = W[(size_t)i * no + j];
-        int rc = buf.get(&net.WT[l], WT.size());
+        int rc = buf.get(&net.WT[l], (size_t)ni * no);
         if (rc) return rc;
-        HIPCHK(hipMemcpy(net.WT[l], WT.data(), WT.size() * sizeof(float), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_transpose, cdiv((int64_t)ni * no, 256), 256, 0, st, ni, no, m->W[l], net.WT[l]);
+        HIPCHK(hipGetLastError());
         net.g_off.push_back(off); off += (size_t)ni * no;
         net.g_off.push_back(off); off += (size_t)no;
     }
@@ -251,14 +288,14 @@ int net_setup(Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const fl
         int rc = buf.get(&net.gamma, (size_t)2 * F);
         if (rc) return rc;
         net.beta = net.gamma + F;
-        HIPCHK(hipMemcpy(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice, st));
         net.g_off.push_back(off); off += F;
         net.g_off.push_back(off); off += F;
     }
     net.g_total = off;
     int rc = buf.get(&net.grads, off);
     if (rc) return rc;
-    HIPCHK(hipMemset(net.grads, 0, off * sizeof(float)));
+    HIPCHK(hipMemsetAsync(net.grads, 0, off * sizeof(float), st));
     return GNN_OK;
 }
 
@@ -305,7 +342,7 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(float) * 2 * F, st));
         HIPCHK(hipMemsetAsync(c.stats, 0, sizeof(float) * 2 * F, st));
         if (n > 0) {
-            const int64_t rpb = 1024;
+            const int64_t rpb = rows_per_block(n);
             dim3 grid(cdiv(F, 32), cdiv(n, rpb));
             hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, h, (const float *)nullptr, (const float *)nullptr, 0, sums, (float *)nullptr, rpb);
             hipLaunchKernelGGL(k_scale_vec, cdiv(F, 64), 64, 0, st, F, sums, 1.0f / (float)n);                       // sums -> batch mean
@@ -327,7 +364,7 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
     const int L = m->n_layers;
     const int64_t n = c.n;
     int rc;
-    const int64_t rpb = 1024;
+    const int64_t rpb = rows_per_block(n);
     if (m->has_bn && n > 0) {
         const int F = m->dims.back();
         float *dgamma = net.grads + net.g_off[2 * L], *dbeta = net.grads + net.g_off[2 * L + 1];
@@ -471,6 +508,14 @@ void gnn_train_ctx_free(gnn_loop *l)
     }
 }
 
+void gnn_train_arena_free(gnn_loop *l)
+{
+    if (l && l->train_arena) {
+        delete static_cast<TrainArena *>(l->train_arena);
+        l->train_arena = nullptr;
+    }
+}
+
 extern "C" int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets, const float *out, const float *sample_weights,
                              double *loss, float *d_out)
 {
@@ -487,7 +532,7 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
                                       const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
                                       float *k_out, float *out_nodes_host)
 {
-    ARGCHK(l && src_indptr && dropout_state && dropout_output && k_out, "bad arguments");
+    ARGCHK(l && dropout_state && dropout_output && k_out, "bad arguments");
     ARGCHK(l->world == 1, "training is single-GPU");
     ARGCHK(l->edge_mode == l->edge_expected, "edge-based net_output: call gnn_loop_set_edge_readout first");
     ARGCHK(!l->st->has_bn || bn_state, "net_state ends with BatchNormalization: gamma|beta required");
@@ -499,17 +544,42 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     HIPCHK(hipSetDevice(l->device));
     hipStream_t st = l->stream;
     gnn_train_ctx_free(l);
+    if (!l->train_arena) l->train_arena = new TrainArena();
+    static_cast<TrainArena *>(l->train_arena)->reset();
     TrainCtx *cx = new TrainCtx();
     l->train_ctx = cx;
+    cx->buf.arena = static_cast<TrainArena *>(l->train_arena);
     Buf &buf = cx->buf;
     Net &ns = cx->ns, &no_ = cx->no_;
     int rc;
-    if ((rc = net_setup(buf, ns, l->st, dropout_state, bn_state)) || (rc = net_setup(buf, no_, l->ou, dropout_output, bn_output))) return rc;
-    // Adjacency by source for the transposed aggregation of the backward pass
-    if ((rc = buf.get(&cx->d_sip, (size_t)N + 1)) || (rc = buf.get(&cx->d_sdst, (size_t)E)) || (rc = buf.get(&cx->d_sw, (size_t)E))) return rc;
-    ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E && (E == 0 || (src_dst && src_w)), "bad by-source CSR");
-    HIPCHK(hipMemcpy(cx->d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
-    if (E) { HIPCHK(hipMemcpy(cx->d_sdst, src_dst, sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(cx->d_sw, src_w, sizeof(float) * E, hipMemcpyHostToDevice)); }
+    if ((rc = net_setup(st, buf, ns, l->st, dropout_state, bn_state)) || (rc = net_setup(st, buf, no_, l->ou, dropout_output, bn_output))) return rc;
+    // Adjacency by source for the transposed aggregation of the backward pass: the caller's arrays, or (NULL) the graph's
+    // own copy, built once from its CSR by destination (a stable counting sort by source keeps destinations ascending)
+    if (src_indptr) {
+        if ((rc = buf.get(&cx->d_sip, (size_t)N + 1)) || (rc = buf.get(&cx->d_sdst, (size_t)E)) || (rc = buf.get(&cx->d_sw, (size_t)E))) return rc;
+        ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E && (E == 0 || (src_dst && src_w)), "bad by-source CSR");
+        HIPCHK(hipMemcpy(cx->d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
+        if (E) { HIPCHK(hipMemcpy(cx->d_sdst, src_dst, sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(cx->d_sw, src_w, sizeof(float) * E, hipMemcpyHostToDevice)); }
+    } else {
+        gnn_graph_shared *sh = g->sh;
+        if (!sh->src_indptr) {
+            std::vector<int32_t> ip((size_t)N + 1), src((size_t)E), sip((size_t)N + 1, 0), sdst((size_t)E);
+            std::vector<float> w((size_t)E), sw((size_t)E);
+            HIPCHK(hipMemcpy(ip.data(), sh->indptr, sizeof(int32_t) * (N + 1), hipMemcpyDeviceToHost));
+            if (E) { HIPCHK(hipMemcpy(src.data(), sh->adj_src, sizeof(int32_t) * E, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(w.data(), sh->adj_w, sizeof(float) * E, hipMemcpyDeviceToHost)); }
+            for (int64_t e = 0; e < E; ++e) ++sip[(size_t)src[e] + 1];
+            for (int64_t i = 0; i < N; ++i) sip[i + 1] += sip[i];
+            std::vector<int32_t> fill(sip.begin(), sip.end() - 1);
+            for (int64_t d = 0; d < N; ++d)
+                for (int32_t e = ip[d]; e < ip[d + 1]; ++e) { const int32_t q = fill[src[e]]++; sdst[q] = (int32_t)d; sw[q] = w[e]; }
+            if (hipMalloc((void **)&sh->src_indptr, sizeof(int32_t) * (N + 1)) != hipSuccess || hipMalloc((void **)&sh->src_dst, sizeof(int32_t) * std::max<int64_t>(E, 1)) != hipSuccess ||
+                hipMalloc((void **)&sh->src_w, sizeof(float) * std::max<int64_t>(E, 1)) != hipSuccess)
+                return gnn_fail(GNN_ERR_HIP, "hipMalloc of the by-source adjacency failed");
+            HIPCHK(hipMemcpy(sh->src_indptr, sip.data(), sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
+            if (E) { HIPCHK(hipMemcpy(sh->src_dst, sdst.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(sh->src_w, sw.data(), sizeof(float) * E, hipMemcpyHostToDevice)); }
+        }
+        cx->d_sip = sh->src_indptr; cx->d_sdst = sh->src_dst; cx->d_sw = sh->src_w;
+    }
 
     // template of the concat with the loop-invariant columns filled in (GNN.py:259, :263)
     float *tmpl = nullptr;

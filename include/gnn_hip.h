@@ -116,7 +116,7 @@ int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, const float
  * evaluate_single_graph(training=True), GNN/GNN.py:180-199): training-mode forward through the unrolled loop (Dropout masks,
  * BatchNormalization batch statistics), loss = sum_i w_i L(t_i, out_i), back-propagation through every executed body.
  *   src_*            Adjacency in CSR form BY SOURCE (rows = source node, inner = destination ascending): the transposed
- *                    aggregation of the backward pass
+ *                    aggregation of the backward pass; all NULL = derived from the graph's own CSR on first use and kept
  *   targets, sample_weights, n_targets   rows = masked nodes (node-based) or graphs (graph-based); loss_kind 0 =
  *                    categorical_crossentropy(from_logits=False), 1 = mean_squared_error
  *   n_graphs, ng_*   NodeGraph^T in CSR form (as gnn_loop_readout) for GNNgraphBased, n_graphs = 0 otherwise

@@ -1,0 +1,46 @@
+"""Wall time of one training step (gnn_loop_train_step through GNNgraphBased.training_step) on MUTAG batches of 32 and on
+a 100k-node synthetic graph.  Run on the GPU box: python tools/bench_train.py"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'gnn_tf_2.x_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+from GNN import losses, optimizers, GNN_utils as utils
+from GNN.GNN import GNNgraphBased, GNNnodeBased
+from GNN.MLP import MLP, set_seed
+from GNN.graph_class import GraphObject, GraphTensor
+import load_MUTAG
+
+set_seed(0)
+graphs = load_MUTAG.load(limit=128)
+batches = [GraphTensor.fromGraphObject(GraphObject.merge(graphs[i:i + 32], problem_based='g', aggregation_mode='average')) for i in range(0, 128, 32)]
+st = MLP(3 + 2 * 14, [32, 32, 14], 'selu', 'glorot_normal', 'zeros', dropout_rate=0.1, dropout_pos=0)
+ou = MLP(14, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
+gnn = GNNgraphBased(net_state=st, net_output=ou, optimizer=optimizers.Adam(0.001), loss_function=losses.categorical_crossentropy, loss_arguments=None,
+                    state_vect_dim=0, max_iteration=10, threshold=0.001, addressed_problem='c')
+for b in batches: gnn.training_step(b, True)
+t = time.perf_counter(); n = 0
+for _ in range(10):
+    for b in batches:
+        r = gnn.training_step(b, True); n += 1
+print('  last k', r['k'], 'loss', r['loss'])
+dt = time.perf_counter() - t
+print(f'MUTAG batch-32 training_step: {1e3 * dt / n:.2f} ms/step  (k={r["k"]}), {32 * n / dt:.0f} graphs/s')
+
+if os.environ.get("SMALL_ONLY"): sys.exit(0)
+N = 100_000
+s = utils.syntheticGraph(N, 10, 3, 1, 2, seed=3)
+arcs = np.concatenate([s['src'][:, None].astype(np.float32), s['dst'][:, None].astype(np.float32), s['arc_labels']], axis=1)
+go = GraphObject(arcs=arcs, nodes=s['nodes'], targets=s['targets'], problem_based='n', aggregation_mode='average')
+if True:
+    gt = GraphTensor.fromGraphObject(go)
+    st = MLP(1 + 2 * (3 + 16), [64, 16], 'selu', 'glorot_normal', 'zeros')
+    ou = MLP(3 + 16, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
+    g2 = GNNnodeBased(net_state=st, net_output=ou, optimizer=optimizers.Adam(0.001), loss_function=losses.categorical_crossentropy, loss_arguments=None,
+                      state_vect_dim=16, max_iteration=5, threshold=0.0, addressed_problem='c')
+    g2.training_step(gt, True)
+    t = time.perf_counter()
+    for _ in range(5):
+        r = g2.training_step(gt, True); print('  k', r['k'], 'loss', r['loss'])
+    dt = (time.perf_counter() - t) / 5
+    print(f'100k-node training_step: {1e3 * dt:.1f} ms/step (k={r["k"]}), {N * r["k"] / dt:.3e} node-updates/s (fwd+bwd)')
