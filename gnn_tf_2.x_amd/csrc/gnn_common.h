@@ -121,6 +121,8 @@ struct gnn_mlp {
     // fused-kernel weight image (see gnn_fused.hip), rebuilt by set_weights
     float *packed = nullptr;
     size_t packed_floats = 0;
+    int *packed_split = nullptr;        // bf16-piece weight image of the split-arithmetic fused kernel (impl 2)
+    size_t packed_split_dwords = 0;
     uint64_t version = 0;
 };
 

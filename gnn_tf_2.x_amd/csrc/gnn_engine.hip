@@ -941,9 +941,9 @@ static int loop_ensure_unfused(gnn_loop *l)
 
 extern "C" int gnn_loop_set_impl(gnn_loop *l, int impl, int *used)
 {
-    ARGCHK(l && (impl == 0 || impl == 1), "impl must be 0 (unfused) or 1 (fused when supported)");
+    ARGCHK(l && impl >= 0 && impl <= 2, "impl must be 0 (unfused), 1 (fused, exact f32 MFMA) or 2 (fused, split bf16 MFMA)");
     l->impl_req = impl;
-    if (used) *used = (impl == 1 && gnn_fused_supported(l)) ? 1 : 0;
+    if (used) *used = (impl >= 1 && gnn_fused_supported(l)) ? impl : 0;
     return GNN_OK;
 }
 
@@ -1120,8 +1120,8 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     gnn_graph *g = l->g;
     const int P = l->world;
     hipStream_t st = l->stream;
-    const bool fused = l->impl_req == 1 && gnn_fused_supported(l);
-    l->impl_used = fused ? 1 : 0;
+    const bool fused = l->impl_req >= 1 && gnn_fused_supported(l);
+    l->impl_used = fused ? l->impl_req : 0;
     int rc = fused ? gnn_fused_prepare(l) : loop_ensure_unfused(l);
     if (rc) return rc;
     if (l->profiling && (int)l->ev.size() < 2 * l->max_iter) {

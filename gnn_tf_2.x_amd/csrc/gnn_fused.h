@@ -31,11 +31,19 @@ struct GnnFusedArgs {
     int *tile_ctr;           // device-wide tile counter of this iteration (zeroed at the start of gnn_loop_run)
     int wstride;             // 1 normally; 0 (GNN_FUSED_DEBUG=1, timing experiments only) makes every K-step re-read step 0
     int stagger;             // s_sleep(127) rounds the second half of the waves waits before its first tile
+    // split arithmetic (impl 2): per layer the bf16-piece weight image [chunk][out tile][piece][lane][8 bf16], and the number
+    // of K = 16 chunks of layer 0
+    const int *Ws[GNN_FUSED_MAXL];
+    int chunks0;
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;
 };
 
 // one per translation unit gnn_fused_l{1,2,3}.hip; false = no instantiation for (act, nt, ntl)
 bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+// split-arithmetic instantiations: gnn_fused_s{1,2,3}.hip
+bool gnn_fused_launch_s1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_s2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_s3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

@@ -2,6 +2,7 @@
 // image, the loop-invariant label block, and the per-iteration launch.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -20,7 +21,12 @@ struct FusedPlan {
     int nt[MAXL] = {0, 0, 0};       // tiles of each layer's output
     int kk[MAXL] = {0, 0, 0};       // K-steps of each layer
     size_t w_off[MAXL] = {0, 0, 0}, b_off[MAXL] = {0, 0, 0}, bn_off = 0, total = 0;
+    // split arithmetic (impl 2): K = 16 chunks per layer and the dword offsets of the bf16-piece images
+    int chunks[MAXL] = {0, 0, 0};
+    size_t s_off[MAXL] = {0, 0, 0}, s_total = 0;
 };
+
+constexpr int S_SLACK = 2;      // zero chunks after the layer-0 block of the split image (layer0_split looks two chunks ahead)
 
 int round_tiles(int width) { return width <= 32 ? 1 : (width <= 64 ? 2 : 4); }
 
@@ -43,7 +49,7 @@ bool make_plan(const gnn_mlp *m, FusedPlan &p)
         if (p.NT > 1 && p.NTL == 1) p.NTL = 2;          // instantiated pairs: (1,1) (2,2) (4,2) (4,4)
     }
     p.kk0 = ((m->dims[0] + 1) / 2 + K_GROUP - 1) / K_GROUP * K_GROUP;
-    p.KP = 2 * p.kk0 + 1;
+    p.KP = std::max(2 * p.kk0, (m->dims[0] + 15) / 16 * 16) + 1;      // odd: conflict-free column reads
     size_t off = 0;
     for (int l = 0; l < p.layers; ++l) {
         p.nt[l] = l == p.layers - 1 ? p.NTL : p.NT;
@@ -55,6 +61,13 @@ bool make_plan(const gnn_mlp *m, FusedPlan &p)
     p.bn_off = off;
     off += 2 * 32 * (size_t)p.NTL;
     p.total = off;
+    size_t soff = 0;
+    for (int l = 0; l < p.layers; ++l) {
+        p.chunks[l] = l == 0 ? (m->dims[0] + 15) / 16 : 2 * p.NT;
+        p.s_off[l] = soff;
+        soff += (size_t)(p.chunks[l] + (l == 0 ? S_SLACK : 0)) * p.nt[l] * 3 * 256;
+    }
+    p.s_total = soff;
     return true;
 }
 
@@ -74,6 +87,7 @@ int gnn_fused_pack(gnn_mlp *m)
     FusedPlan p;
     if (!make_plan(m, p)) { gnn_fused_release(m); return GNN_OK; }
     std::vector<float> img(p.total, 0.0f);
+    std::vector<uint32_t> simg(p.s_total, 0u);
     std::vector<float> W, b;
     for (int l = 0; l < m->n_layers; ++l) {
         const int n_in = m->dims[l], n_out = m->dims[l + 1];
@@ -90,6 +104,27 @@ int gnn_fused_pack(gnn_mlp *m)
                     wp[((size_t)kk * 64 + lane) * nt + jt] = (k < n_in && j < n_out) ? W[(size_t)k * n_out + j] : 0.0f;
                 }
         for (int j = 0; j < n_out; ++j) img[p.b_off[l] + j] = b[j];
+        // split image: [chunk][out tile][piece][lane][8 bf16]; element i of lane (m, h) is k(h, i) of gnn_fused_kernel.h
+        uint32_t *sp = simg.data() + p.s_off[l];
+        for (int c = 0; c < p.chunks[l]; ++c)
+            for (int jt = 0; jt < nt; ++jt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int h = lane >> 5, r = 8 * (c & 1) + i;
+                        const int k = l == 0 ? 16 * c + 8 * h + i : 32 * (c >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int j = 32 * jt + (lane & 31);
+                        float v = (k < n_in && j < n_out) ? W[(size_t)k * n_out + j] : 0.0f;
+                        for (int pc = 0; pc < 3; ++pc) {          // truncation split: v == p0 + p1 + p2 exactly
+                            uint32_t bits;
+                            memcpy(&bits, &v, 4);
+                            const uint32_t hi = bits & 0xffff0000u;
+                            float piece;
+                            memcpy(&piece, &hi, 4);
+                            v = v - piece;
+                            uint32_t &d = sp[((((size_t)c * nt + jt) * 3 + pc) * 64 + lane) * 4 + i / 2];
+                            d |= (i & 1) ? hi : (hi >> 16);
+                        }
+                    }
     }
     if (m->has_bn) {
         const int f = m->dims.back();
@@ -102,14 +137,24 @@ int gnn_fused_pack(gnn_mlp *m)
         m->packed_floats = p.total;
     }
     HIPCHK(hipMemcpy(m->packed, img.data(), p.total * sizeof(float), hipMemcpyHostToDevice));
+    if (m->packed_split_dwords != p.s_total) {
+        if (m->packed_split) (void)hipFree(m->packed_split);
+        m->packed_split = nullptr;
+        HIPCHK(hipMalloc((void **)&m->packed_split, p.s_total * sizeof(uint32_t)));
+        m->packed_split_dwords = p.s_total;
+    }
+    HIPCHK(hipMemcpy(m->packed_split, simg.data(), p.s_total * sizeof(uint32_t), hipMemcpyHostToDevice));
     return GNN_OK;
 }
 
 void gnn_fused_release(gnn_mlp *m)
 {
     if (m->packed) (void)hipFree(m->packed);
+    if (m->packed_split) (void)hipFree(m->packed_split);
     m->packed = nullptr;
+    m->packed_split = nullptr;
     m->packed_floats = 0;
+    m->packed_split_dwords = 0;
 }
 
 bool gnn_fused_supported(const gnn_loop *l)
@@ -169,6 +214,9 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         a.Wp[i] = m->packed + p.w_off[i];
         a.bias[i] = m->packed + p.b_off[i];
     }
+    const bool split = l->impl_req == 2;
+    for (int i = 0; i < p.layers; ++i) a.Ws[i] = m->packed_split + p.s_off[i];
+    a.chunks0 = p.chunks[0];
     a.bn_scale = m->has_bn ? m->packed + p.bn_off : nullptr;
     a.bn_shift = m->has_bn ? m->packed + p.bn_off + 32 * p.NTL : nullptr;
     a.thr = l->thr;
@@ -199,7 +247,11 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_env : 0;   // only when every wave has several tiles to run
     const size_t lds = lds_bytes(p);
     bool ok = false;
-    if (p.layers == 1) ok = gnn_fused_launch_l1(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
+    if (split) {
+        if (p.layers == 1) ok = gnn_fused_launch_s1(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
+        else if (p.layers == 2) ok = gnn_fused_launch_s2(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
+        else ok = gnn_fused_launch_s3(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
+    } else if (p.layers == 1) ok = gnn_fused_launch_l1(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     else if (p.layers == 2) ok = gnn_fused_launch_l2(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     else ok = gnn_fused_launch_l3(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);

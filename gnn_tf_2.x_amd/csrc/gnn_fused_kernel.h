@@ -272,6 +272,134 @@ __device__ __forceinline__ void layer_from_regs(f32x16 (&hin)[NI], const float *
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// SPLIT arithmetic (impl 2): fp32 operands as three bf16 pieces on v_mfma_f32_32x32x16_bf16.
+//
+// The f32 MFMA of gfx950 issues at the f32 VALU rate and shares its pipe; the bf16 MFMA is 13x faster per K and overlaps
+// the partner wave's VALU work.  Every fp32 value v is cut, by truncation, into p0 + p1 + p2 == v EXACTLY (8 + 8 + 8
+// mantissa bits; the remainders v - p0 and v - p0 - p1 are exact in fp32), products of pieces are exact in the fp32
+// accumulator, and of the nine piece products of x * w the six of relative weight >= 2^-16 are accumulated
+// (p0q0, p0q1, p1q0, p1q1, p0q2, p2q0); the dropped ones are <= 3 * 2^-24 |x w|, the size of one fp32 rounding.  What
+// differs from the oracle's fmaf chain is therefore only the accumulation order inside the matrix unit: results agree
+// to fp32 rounding noise (tests: 1e-5 against the float64 oracle), not bit for bit.  The exact f32-MFMA path stays
+// available as impl 1.
+//
+// Operand layout of the 32x32x16 MFMA: lane l carries 8 consecutive k of row / column l & 31, k group l >> 5.  Which k
+// sits where is free as long as weights (A) and activations (B) agree, so the k order of a hidden layer is simply the
+// order in which the previous layer's accumulator already holds the features (no cross-lane exchange at all):
+//   layer 0, chunk c:                  k(h, i) = 16 c + 8 h + i                      (LDS tile column)
+//   hidden, chunk c = 2 ti + q:        k(h, i) = 32 ti + (r & 3) + 8 (r >> 2) + 4 h,  r = 8 q + i   (accumulator register r)
+// gnn_fused.hip packs the weight pieces in the same order: [chunk][out tile][piece][lane][8 bf16].
+// ---------------------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v4i gload4i(const int *p) { return *(const GNN_GLOBAL v4i *)p; }
+
+__device__ __forceinline__ void split8(const float (&v)[8], v4i &p0, v4i &p1, v4i &p2)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned a = __float_as_uint(v[2 * j]), b = __float_as_uint(v[2 * j + 1]);
+        const float ar = v[2 * j] - __uint_as_float(a & 0xffff0000u), br = v[2 * j + 1] - __uint_as_float(b & 0xffff0000u);
+        const unsigned aru = __float_as_uint(ar), bru = __float_as_uint(br);
+        const float ar2 = ar - __uint_as_float(aru & 0xffff0000u), br2 = br - __uint_as_float(bru & 0xffff0000u);
+        // high halves of (even, odd) element into the (low, high) half of one dword
+        p0[j] = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
+        p1[j] = (int)__builtin_amdgcn_perm(bru, aru, 0x07060302u);
+        p2[j] = (int)__builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(v4i a, v4i b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// the six piece products of one K = 16 chunk on T output tiles; consecutive MFMAs go to different accumulators
+template <int T>
+__device__ __forceinline__ void mfma_split(const v4i (&w)[T][3], v4i b0, v4i b1, v4i b2, f32x16 *acc)
+{
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = mfma_bf16(w[t][0], b2, acc[t]);      // smallest terms first
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = mfma_bf16(w[t][2], b0, acc[t]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = mfma_bf16(w[t][1], b1, acc[t]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = mfma_bf16(w[t][0], b1, acc[t]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = mfma_bf16(w[t][1], b0, acc[t]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = mfma_bf16(w[t][0], b0, acc[t]);
+}
+
+// layer 0: input = LDS tile.  xr = X + (lane & 31) * KP + 8 * (lane >> 5); wl = split image of the layer + 4 * lane.
+// Two register sets: the weights / tile values of chunk c + 1 are requested before the MFMAs of chunk c.  The image has
+// two zero chunks of slack and the LDS allocation 128 B, so the look-ahead never leaves them; it is never consumed.
+template <int NO>
+__device__ __forceinline__ void layer0_split(const float *xr, const int *wl, int n_chunks, f32x16 (&acc)[NO])
+{
+    v4i wa[NO][3], wb[NO][3];
+    float xa[8], xb[8];
+#define GNN_S0_LOAD(W, XV, C)                                                                       \
+    _Pragma("unroll") for (int jt = 0; jt < NO; ++jt)                                               \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                            \
+            W[jt][pc] = gload4i(wl + (size_t)(((C) * NO + jt) * 3 + pc) * 256);                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) XV[i] = xr[16 * (C) + i];                         \
+    __builtin_amdgcn_sched_barrier(0);
+#define GNN_S0_MFMA(W, XV)                                                                          \
+    {                                                                                               \
+        v4i b0, b1, b2;                                                                             \
+        split8(XV, b0, b1, b2);                                                                     \
+        mfma_split<NO>(W, b0, b1, b2, acc);                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                          \
+    }
+    GNN_S0_LOAD(wa, xa, 0)
+    for (int c = 0; c < n_chunks; c += 2) {
+        GNN_S0_LOAD(wb, xb, c + 1)
+        GNN_S0_MFMA(wa, xa)
+        GNN_S0_LOAD(wa, xa, c + 2)
+        if (c + 1 < n_chunks) GNN_S0_MFMA(wb, xb)
+    }
+#undef GNN_S0_LOAD
+#undef GNN_S0_MFMA
+}
+
+// hidden / last layer: input = accumulator tiles of the previous layer; its epilogue (bias + activation) is applied here.
+// Units of (chunk, pair of output tiles), fully unrolled, weights requested DEPTH units ahead.
+template <int NI, int NO, int ACT>
+__device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const float *bias_prev, int half, f32x16 (&acc)[NO],
+                                                      const int *wl)
+{
+    constexpr int TPU = NO >= 2 ? 2 : 1, UPC = NO / TPU, CH = 2 * NI, U = CH * UPC, DEPTH = 3;
+    v4i w[U][TPU][3];
+#define GNN_S1_LOAD(UU)                                                                             \
+    _Pragma("unroll") for (int t = 0; t < TPU; ++t)                                                 \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                            \
+            w[UU][t][pc] = gload4i(wl + (size_t)((((UU) / UPC) * NO + ((UU) % UPC) * TPU + t) * 3 + pc) * 256);
+#pragma unroll
+    for (int u = 0; u < DEPTH && u < U; ++u) { GNN_S1_LOAD(u) }
+#pragma unroll
+    for (int ti = 0; ti < NI; ++ti) tile_epilogue<ACT, false>(hin[ti], bias_prev, nullptr, nullptr, ti, half);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = hin[c >> 1][8 * (c & 1) + i];
+        v4i b0, b1, b2;
+        split8(v, b0, b1, b2);
+#pragma unroll
+        for (int up = 0; up < UPC; ++up) {
+            const int u = c * UPC + up;
+            if (u + DEPTH < U) { GNN_S1_LOAD(u + DEPTH) }
+            mfma_split<TPU>(w[u], b0, b1, b2, &acc[up * TPU]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef GNN_S1_LOAD
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // tile load + gather.  X[32][KP] columns: [state | nodes? | aggregated state | aggregated nodes? | aggregated arcs | 0 pad]
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -567,7 +695,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N])
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
 }
 
-template <int LAYERS, int NT, int NTL, int ACT>
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
 __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedArgs a0)
 {
     const GnnFusedArgs &a = a0;      // (shadowed inside the tile loop)
@@ -627,7 +755,30 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     const int half = lane >> 5;
     const float *xb = X + (lane & 31) * KP + half;
     f32x16 out[NTL];
-    if constexpr (LAYERS == 1) {
+    if constexpr (SPLIT) {
+        asm volatile("" : "+s"(a.Ws[0]), "+s"(a.Ws[1]), "+s"(a.Ws[2]));
+        const float *xr = X + (lane & 31) * KP + 8 * half;
+        if constexpr (LAYERS == 1) {
+            zero_acc<NTL>(out);
+            layer0_split<NTL>(xr, a.Ws[0] + 4 * lane, a.chunks0, out);
+        } else {
+            f32x16 h1[NT];
+            zero_acc<NT>(h1);
+            layer0_split<NT>(xr, a.Ws[0] + 4 * lane, a.chunks0, h1);
+            GNN_STAMP(3);
+            GNN_STAMP(4);
+            if constexpr (LAYERS == 2) {
+                zero_acc<NTL>(out);
+                layer_split_from_regs<NT, NTL, ACT>(h1, a.bias[0], half, out, a.Ws[1] + 4 * lane);
+            } else {
+                f32x16 h2[NT];
+                zero_acc<NT>(h2);
+                layer_split_from_regs<NT, NT, ACT>(h1, a.bias[0], half, h2, a.Ws[1] + 4 * lane);
+                zero_acc<NTL>(out);
+                layer_split_from_regs<NT, NTL, ACT>(h2, a.bias[1], half, out, a.Ws[2] + 4 * lane);
+            }
+        }
+    } else if constexpr (LAYERS == 1) {
         zero_acc<NTL>(out);
         layer_from_lds<NTL>(xb, a.Wp[0] + (size_t)lane * NTL, a.kk0, out, a.wstride);
     } else {
@@ -672,47 +823,47 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
   }
 }
 
-template <int LAYERS, int NT, int NTL, int ACT>
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
 inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
     static bool raised = false;   // dynamic LDS above 64 KiB has to be requested once per kernel
     if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT, SPLIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         raised = true;
     }
-    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
+    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
 }
 
 // (NT, NTL) pairs that are instantiated; gnn_fused.hip rounds every net up to one of them
-template <int LAYERS, int ACT>
+template <int LAYERS, int ACT, bool SPLIT>
 inline bool launch_tiles(int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
     if constexpr (LAYERS == 1) {
-        if (ntl == 1) launch<1, 1, 1, ACT>(a, grid, lds_bytes, st);
-        else if (ntl == 2) launch<1, 2, 2, ACT>(a, grid, lds_bytes, st);
-        else if (ntl == 4) launch<1, 4, 4, ACT>(a, grid, lds_bytes, st);
+        if (ntl == 1) launch<1, 1, 1, ACT, SPLIT>(a, grid, lds_bytes, st);
+        else if (ntl == 2) launch<1, 2, 2, ACT, SPLIT>(a, grid, lds_bytes, st);
+        else if (ntl == 4) launch<1, 4, 4, ACT, SPLIT>(a, grid, lds_bytes, st);
         else return false;
     } else {
-        if (nt == 1 && ntl == 1) launch<LAYERS, 1, 1, ACT>(a, grid, lds_bytes, st);
-        else if (nt == 2 && ntl == 2) launch<LAYERS, 2, 2, ACT>(a, grid, lds_bytes, st);
-        else if (nt == 4 && ntl == 2) launch<LAYERS, 4, 2, ACT>(a, grid, lds_bytes, st);
-        else if (nt == 4 && ntl == 4) launch<LAYERS, 4, 4, ACT>(a, grid, lds_bytes, st);
+        if (nt == 1 && ntl == 1) launch<LAYERS, 1, 1, ACT, SPLIT>(a, grid, lds_bytes, st);
+        else if (nt == 2 && ntl == 2) launch<LAYERS, 2, 2, ACT, SPLIT>(a, grid, lds_bytes, st);
+        else if (nt == 4 && ntl == 2) launch<LAYERS, 4, 2, ACT, SPLIT>(a, grid, lds_bytes, st);
+        else if (nt == 4 && ntl == 4) launch<LAYERS, 4, 4, ACT, SPLIT>(a, grid, lds_bytes, st);
         else return false;
     }
     return true;
 }
 
-template <int LAYERS>
+template <int LAYERS, bool SPLIT>
 inline bool launch_act(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
     switch (act) {
-    case GNN_ACT_LINEAR: return launch_tiles<LAYERS, GNN_ACT_LINEAR>(nt, ntl, a, grid, lds_bytes, st);
-    case GNN_ACT_RELU: return launch_tiles<LAYERS, GNN_ACT_RELU>(nt, ntl, a, grid, lds_bytes, st);
-    case GNN_ACT_SELU: return launch_tiles<LAYERS, GNN_ACT_SELU>(nt, ntl, a, grid, lds_bytes, st);
-    case GNN_ACT_ELU: return launch_tiles<LAYERS, GNN_ACT_ELU>(nt, ntl, a, grid, lds_bytes, st);
-    case GNN_ACT_TANH: return launch_tiles<LAYERS, GNN_ACT_TANH>(nt, ntl, a, grid, lds_bytes, st);
-    case GNN_ACT_SIGMOID: return launch_tiles<LAYERS, GNN_ACT_SIGMOID>(nt, ntl, a, grid, lds_bytes, st);
+    case GNN_ACT_LINEAR: return launch_tiles<LAYERS, GNN_ACT_LINEAR, SPLIT>(nt, ntl, a, grid, lds_bytes, st);
+    case GNN_ACT_RELU: return launch_tiles<LAYERS, GNN_ACT_RELU, SPLIT>(nt, ntl, a, grid, lds_bytes, st);
+    case GNN_ACT_SELU: return launch_tiles<LAYERS, GNN_ACT_SELU, SPLIT>(nt, ntl, a, grid, lds_bytes, st);
+    case GNN_ACT_ELU: return launch_tiles<LAYERS, GNN_ACT_ELU, SPLIT>(nt, ntl, a, grid, lds_bytes, st);
+    case GNN_ACT_TANH: return launch_tiles<LAYERS, GNN_ACT_TANH, SPLIT>(nt, ntl, a, grid, lds_bytes, st);
+    case GNN_ACT_SIGMOID: return launch_tiles<LAYERS, GNN_ACT_SIGMOID, SPLIT>(nt, ntl, a, grid, lds_bytes, st);
     default: return false;
     }
 }

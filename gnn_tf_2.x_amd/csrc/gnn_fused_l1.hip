@@ -3,5 +3,5 @@
 
 bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
-    return gnn_fused_dev::launch_act<1>(act, nt, ntl, a, grid, lds_bytes, st);
+    return gnn_fused_dev::launch_act<1, false>(act, nt, ntl, a, grid, lds_bytes, st);
 }

@@ -90,6 +90,32 @@ def test_loop_bit_exact_vs_c_oracle(impl, d, nl, al, hidden, act, mode, sort):
     assert np.max(np.abs(s - s64)) < 1e-5 and np.max(np.abs(o - o64)) < 1e-5
 
 
+@pytest.mark.parametrize('d,nl,al,hidden,act,mode,sort', [
+    (0, 3, 1, (), 'selu', 'average', True),
+    (0, 14, 3, (32, 32), 'selu', 'average', True),
+    (8, 3, 2, (16,), 'tanh', 'sum', False),
+    (5, 2, 1, (7, 9), 'relu', 'normalized', False),
+    (64, 3, 1, (128, 128), 'selu', 'average', True),   # BASELINE config 3 shape
+    (64, 5, 1, (128, 128), 'selu', 'average', True),
+    (32, 4, 0, (64,), 'sigmoid', 'average', True),
+    (16, 3, 1, (40, 72), 'elu', 'average', True),      # K = 39 -> 3 chunks (odd), hidden widths that are not tile multiples
+])
+def test_loop_split_arithmetic_within_tolerance(d, nl, al, hidden, act, mode, sort):
+    """impl 2: the dense layers run on the bf16 MFMA with every fp32 operand cut into three exact bf16 pieces (six piece
+    products per term, fp32 accumulate).  Same k; states / outputs within 1e-5 of the float64 oracle (BASELINE north_star
+    tolerance) and within fp32 rounding noise of the exact path."""
+    rng = np.random.default_rng(1000 + 7 * d + nl)
+    g, st, ou, s0 = _case(rng, n=700, d=d, nl=nl, al=al, hidden=hidden, act=act, sort=sort, mode=mode)
+    g['set_mask'] = rng.random(700) < 0.8
+    g['output_mask'] = rng.random(700) < 0.7
+    k, s, o = _run_hip(g, st, ou, d, 30, 0.01, s0, 2)
+    k1, s1, o1 = _run_hip(g, st, ou, d, 30, 0.01, s0, 1)
+    k64, s64, o64 = orc.loop_node(g, st, ou, d, 30, 0.01, s0, np.float64)
+    assert k == k64 == k1
+    assert np.max(np.abs(s - s64)) < 1e-5 and np.max(np.abs(o - o64)) < 1e-5
+    assert np.max(np.abs(s - s1)) < 2e-6 * max(1.0, np.max(np.abs(s1)))
+
+
 @pytest.mark.parametrize('impl', [0, 1])
 def test_loop_edge_cases(impl):
     rng = np.random.default_rng(5)
