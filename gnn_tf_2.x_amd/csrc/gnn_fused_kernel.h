@@ -370,7 +370,8 @@ template <int NI, int NO, int ACT>
 __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const float *bias_prev, int half, f32x16 (&acc)[NO],
                                                       const int *wl)
 {
-    constexpr int TPU = NO >= 2 ? 2 : 1, UPC = NO / TPU, CH = 2 * NI, U = CH * UPC, DEPTH = 3;
+    constexpr int TPU = NO >= 2 ? 2 : 1, UPC = NO / TPU, CH = 2 * NI, U = CH * UPC;
+    constexpr int DEPTH = (NI + NO >= 8) ? 2 : 3;       // 24 VGPRs per unit in flight next to 16 (NI + NO) of activations
     v4i w[U][TPU][3];
 #define GNN_S1_LOAD(UU)                                                                             \
     _Pragma("unroll") for (int t = 0; t < TPU; ++t)                                                 \
