@@ -116,9 +116,31 @@ __device__ __forceinline__ float act_t(float v)
     }
 }
 
+// Activations of the split-arithmetic path (tolerance-based parity, so the hardware transcendentals are admissible):
+// v_exp_f32 / v_rcp_f32 are accurate to 1 ulp; the formulas are those of gnn_act.
+template <int ACT>
+__device__ __forceinline__ float act_fast(float v)
+{
+    constexpr float LOG2E = 1.44269504088896341f, SCALE = 1.0507009873554805f, ALPHA = 1.6732632423543772f;
+    if constexpr (ACT == GNN_ACT_SELU) {
+        const float e = __builtin_amdgcn_exp2f(v * LOG2E);
+        return v > 0.0f ? SCALE * v : __builtin_fmaf(e, SCALE * ALPHA, -(SCALE * ALPHA));
+    } else if constexpr (ACT == GNN_ACT_ELU) {
+        return v > 0.0f ? v : __builtin_amdgcn_exp2f(v * LOG2E) - 1.0f;
+    } else if constexpr (ACT == GNN_ACT_SIGMOID) {
+        return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -LOG2E));
+    } else if constexpr (ACT == GNN_ACT_TANH) {
+        const float t = __builtin_amdgcn_exp2f(__builtin_fabsf(v) * (-2.0f * LOG2E));
+        const float q = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+        return v < 0.0f ? -q : q;
+    } else {
+        return gnn_act(v, ACT);
+    }
+}
+
 // bias + activation (+ BatchNormalization when BN) on one accumulator tile; feature of register r on this lane:
 // 32 jt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-template <int ACT, bool BN>
+template <int ACT, bool BN, bool FAST = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, const float *bn_scale, const float *bn_shift,
                                               int jt, int half)
 {
@@ -136,7 +158,7 @@ __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, cons
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float v = a[4 * q + t] + bb[t];
-            v = act_t<ACT>(v);
+            v = FAST ? act_fast<ACT>(v) : act_t<ACT>(v);
             if (BN) { const float m = v * sc[t]; v = m + sh[t]; }
             a[4 * q + t] = v;
         }
@@ -290,6 +312,9 @@ __device__ __forceinline__ void layer_from_regs(f32x16 (&hin)[NI], const float *
 //   hidden, chunk c = 2 ti + q:        k(h, i) = 32 ti + (r & 3) + 8 (r >> 2) + 4 h,  r = 8 q + i   (accumulator register r)
 // gnn_fused.hip packs the weight pieces in the same order: [chunk][out tile][piece][lane][8 bf16].
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef GNN_SPLIT_DEPTH44
+#define GNN_SPLIT_DEPTH44 1   // measured: depth 2 spills ~40 VGPRs and is slower
+#endif
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ v4i gload4i(const int *p) { return *(const GNN_GLOBAL v4i *)p; }
@@ -364,40 +389,95 @@ __device__ __forceinline__ void layer0_split(const float *xr, const int *wl, int
 #undef GNN_S0_MFMA
 }
 
-// hidden / last layer: input = accumulator tiles of the previous layer; its epilogue (bias + activation) is applied here.
+// one (even, odd) element pair of split8: pieces of v0, v1 into dword j of the three operands
+__device__ __forceinline__ void split_pair(float v0, float v1, int &p0, int &p1, int &p2)
+{
+    const unsigned a = __float_as_uint(v0), b = __float_as_uint(v1);
+    const float ar = v0 - __uint_as_float(a & 0xffff0000u), br = v1 - __uint_as_float(b & 0xffff0000u);
+    const unsigned aru = __float_as_uint(ar), bru = __float_as_uint(br);
+    const float ar2 = ar - __uint_as_float(aru & 0xffff0000u), br2 = br - __uint_as_float(bru & 0xffff0000u);
+    p0 = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
+    p1 = (int)__builtin_amdgcn_perm(bru, aru, 0x07060302u);
+    p2 = (int)__builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302u);
+}
+
+// hidden / last layer: input = accumulator tiles of the previous layer; its epilogue (bias + activation) is applied here,
+// software-pipelined in program order against this layer's MFMAs (the wave issues in order; VALU work placed right after
+// an MFMA runs while the matrix pipe executes it): while the 6 NO MFMAs of chunk c are issued, the 8 elements of chunk
+// c + 2 get bias + activation (E) and the elements of chunk c + 1 are cut into bf16 pieces (S), one task per few MFMAs.
 // Units of (chunk, pair of output tiles), fully unrolled, weights requested DEPTH units ahead.
 template <int NI, int NO, int ACT>
 __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const float *bias_prev, int half, f32x16 (&acc)[NO],
                                                       const int *wl)
 {
     constexpr int TPU = NO >= 2 ? 2 : 1, UPC = NO / TPU, CH = 2 * NI, U = CH * UPC;
-    constexpr int DEPTH = (NI + NO >= 8) ? 2 : 3;       // 24 VGPRs per unit in flight next to 16 (NI + NO) of activations
+    constexpr int DEPTH = (NI + NO >= 8) ? GNN_SPLIT_DEPTH44 : 3;       // 24 VGPRs per unit in flight next to 16 (NI + NO) of activations
+    constexpr int NM = 6 * NO, NTASK = 12;              // MFMAs per chunk; VALU tasks per chunk: 8 E elements, then 4 S pairs (late:
+                                                        // the pieces of chunk c + 1 become live when b2 / b1 of chunk c are dead)
     v4i w[U][TPU][3];
+    int bp[2][3][4];                                    // operand pieces of chunk c (bp[c & 1]) and c + 1
+    float eb[8];                                        // biases of the elements of chunk c + 2
 #define GNN_S1_LOAD(UU)                                                                             \
     _Pragma("unroll") for (int t = 0; t < TPU; ++t)                                                 \
         _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                            \
             w[UU][t][pc] = gload4i(wl + (size_t)((((UU) / UPC) * NO + ((UU) % UPC) * TPU + t) * 3 + pc) * 256);
+#define GNN_S1_BIAS(C, DST)                                                                         \
+    {                                                                                               \
+        const v4f q0 = gload4(bias_prev + 32 * ((C) >> 1) + 16 * ((C) & 1) + 4 * half);             \
+        const v4f q1 = gload4(bias_prev + 32 * ((C) >> 1) + 16 * ((C) & 1) + 8 + 4 * half);         \
+        DST[0] = q0.x; DST[1] = q0.y; DST[2] = q0.z; DST[3] = q0.w;                                 \
+        DST[4] = q1.x; DST[5] = q1.y; DST[6] = q1.z; DST[7] = q1.w;                                 \
+    }
+#define GNN_S1_E(C, I, B) hin[(C) >> 1][8 * ((C) & 1) + (I)] = act_fast<ACT>(hin[(C) >> 1][8 * ((C) & 1) + (I)] + B[I]);
+#define GNN_S1_S(C, J, DST) split_pair(hin[(C) >> 1][8 * ((C) & 1) + 2 * (J)], hin[(C) >> 1][8 * ((C) & 1) + 2 * (J) + 1], DST[0][J], DST[1][J], DST[2][J]);
 #pragma unroll
     for (int u = 0; u < DEPTH && u < U; ++u) { GNN_S1_LOAD(u) }
+    {   // prologue: E(0), S(0), E(1); biases of chunk 2
+        float b0[8], b1[8];
+        GNN_S1_BIAS(0, b0)
+        GNN_S1_BIAS(1, b1)
 #pragma unroll
-    for (int ti = 0; ti < NI; ++ti) tile_epilogue<ACT, false>(hin[ti], bias_prev, nullptr, nullptr, ti, half);
+        for (int i = 0; i < 8; ++i) { GNN_S1_E(0, i, b0) }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { GNN_S1_S(0, j, bp[0]) }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { GNN_S1_E(1, i, b1) }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-        float v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = hin[c >> 1][8 * (c & 1) + i];
-        v4i b0, b1, b2;
-        split8(v, b0, b1, b2);
+        if (c + 2 < CH) GNN_S1_BIAS(c + 2, eb)                     // consumed from the first MFMAs of this chunk on
 #pragma unroll
         for (int up = 0; up < UPC; ++up) {
             const int u = c * UPC + up;
             if (u + DEPTH < U) { GNN_S1_LOAD(u + DEPTH) }
-            mfma_split<TPU>(w[u], b0, b1, b2, &acc[up * TPU]);
-            __builtin_amdgcn_sched_barrier(0);
+            // term order as mfma_split: smallest products first
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+#pragma unroll
+                for (int t = 0; t < TPU; ++t) {
+                    const int *bq = bp[c & 1][PB[term]];
+                    acc[up * TPU + t] = mfma_bf16(w[u][t][PA[term]], v4i{bq[0], bq[1], bq[2], bq[3]}, acc[up * TPU + t]);
+                    // VALU tasks due after MFMA number m of the chunk: [(m - 1) NTASK / NM, m NTASK / NM)
+                    const int m = (up * 6 + term) * TPU + t + 1;
+                    const int k0 = (m - 1) * NTASK / NM, k1 = m * NTASK / NM;
+#pragma unroll
+                    for (int k = 0; k < NTASK; ++k) {
+                        if (k >= k0 && k < k1) {
+                            if (k < 8) { if (c + 2 < CH) { GNN_S1_E(c + 2, k, eb) } }
+                            else { if (c + 1 < CH) { GNN_S1_S(c + 1, k - 8, bp[(c + 1) & 1]) } }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
 #undef GNN_S1_LOAD
+#undef GNN_S1_BIAS
+#undef GNN_S1_E
+#undef GNN_S1_S
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -804,8 +884,8 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     GNN_STAMP(5);
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt) {
-        if (a.bn_scale) tile_epilogue<ACT, true>(out[jt], a.bias[LAYERS - 1], a.bn_scale, a.bn_shift, jt, half);
-        else tile_epilogue<ACT, false>(out[jt], a.bias[LAYERS - 1], nullptr, nullptr, jt, half);
+        if (a.bn_scale) tile_epilogue<ACT, true, SPLIT>(out[jt], a.bias[LAYERS - 1], a.bn_scale, a.bn_shift, jt, half);
+        else tile_epilogue<ACT, false, SPLIT>(out[jt], a.bias[LAYERS - 1], nullptr, nullptr, jt, half);
         float *x = X + (lane & 31) * KP + c_aggs;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
