@@ -98,7 +98,8 @@ def main():
     ap.add_argument('--nodes', type=int, default=1_000_000)
     ap.add_argument('--arcs-per-node', type=float, default=10.0)
     ap.add_argument('--max-iter', type=int, default=30)
-    ap.add_argument('--impl', type=int, default=1, help='1: fused kernel (default), 0: one kernel per TF op')
+    ap.add_argument('--impl', type=int, default=2, help='2: fused kernel, split bf16 MFMA (default, what the engine runs by default); '
+                                                       '1: fused kernel, bit-exact f32 MFMA; 0: one kernel per TF op')
     ap.add_argument('--act', default='selu', help='net_state activation (experiments; the BASELINE config is selu)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=20)
@@ -130,8 +131,9 @@ def main():
     n_arcs_local = len(adj_src)
     graph = engine.Graph(n, indptr, adj_src, adj_w, arc_w, arc_lab, s['nodes'], np.ones(nr, np.uint8), row_begin=rb,
                          device=local_rank)
-    loop = engine.Loop(graph, engine.Mlp(st['weights'], st['activations'], True, device=local_rank),
-                       engine.Mlp(ou['weights'], ou['activations'], True, device=local_rank), d, args.max_iter, 0.0, comm)
+    mst = engine.Mlp(st['weights'], st['activations'], True, device=local_rank)
+    mou = engine.Mlp(ou['weights'], ou['activations'], True, device=local_rank)
+    loop = engine.Loop(graph, mst, mou, d, args.max_iter, 0.0, comm)
     impl_used = loop.set_impl(args.impl)
     loop.set_state0(state0[rb:rb + nr])
 
@@ -151,6 +153,35 @@ def main():
     elapsed = barrier(time.perf_counter() - t0)          # device sync, then max over ranks
     loop.set_profiling(False)
 
+    # the bit-exact fused path (impl 1) on the same inputs, one untimed + one timed Loop: reported beside the headline, and
+    # the two final states are compared (the default path must stay within fp32 rounding noise of the exact one)
+    exact = None
+    if world == 1 and impl_used == 2:
+        final_default = loop.state()
+        loop.set_impl(1)
+        loop.run()
+        barrier()
+        t2 = time.perf_counter()
+        k_x = loop.run()
+        barrier()
+        dt = time.perf_counter() - t2
+        final_exact = loop.state()
+        exact = {'updates_per_s': n * k_x / dt, 'ms_per_step': 1e3 * dt,
+                 'max_abs_state_difference_to_default_path': float(np.max(np.abs(final_exact - final_default))),
+                 'max_abs_state': float(np.max(np.abs(final_exact))),
+                 'note': 'random-init weights give an expansive state map: after 30 bodies the exact f32 path itself is about as '
+                         'far from float64; one body (below) shows the arithmetic difference proper'}
+        loop.set_impl(2)
+        one = engine.Loop(graph, mst, mou, d, 1, 0.0)
+        one.set_state0(state0)
+        one.run()
+        s2 = one.state()
+        one.set_impl(1)
+        one.run()
+        exact['max_abs_state_difference_after_one_body'] = float(np.max(np.abs(one.state() - s2)))
+        one.close()
+        del final_exact, final_default, s2
+
     # boundary-inclusive rate (never `value`): host state0 in, host state + output back, one Loop (DESIGN.md "Measurement")
     t1 = time.perf_counter()
     loop.set_state0(state0[rb:rb + nr])
@@ -167,7 +198,7 @@ def main():
         # (tools/profile.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if world == 1 and impl_used and args.nodes == 1_000_000 and os.path.exists(tpath):
+        if world == 1 and impl_used == 2 and args.nodes == 1_000_000 and os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get('hbm_bytes_per_launch')
             traffic_src = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)'
@@ -181,7 +212,11 @@ def main():
                                    f'max_iter={args.max_iter}, threshold=0 (all iterations run)',
                        'iterations_per_step': k_total / args.steps,
                        'parallelism': f'node-range shards x{world}, RCCL all-gather of state rows per iteration' if world > 1 else 'single GPU',
-                       'impl': 'fused gather+MLP kernel' if impl_used else 'one kernel per TF op (unfused)',
+                       'impl': {2: 'fused gather+MLP kernel, dense layers on the bf16 MFMA with fp32 operands cut into 3 exact bf16 '
+                                   'pieces (6 piece products, fp32 accumulate; error per product <= 3*2^-24)',
+                                1: 'fused gather+MLP kernel, dense layers on the f32 MFMA (bit-identical to the oracle)',
+                                0: 'one kernel per TF op (unfused)'}[impl_used],
+                       'exact_f32_mfma_path': exact,
                        'pcie_inclusive_updates_per_s': nr * k_e2e / e2e_s},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,

@@ -39,7 +39,7 @@ class GNNnodeBased(BaseClass):
         self.state_vect_dim = state_vect_dim
         self.seed = 0
         self.device = 0
-        self.impl = 1           # 1: fused kernel when the shapes allow it, 0: one kernel per TF op
+        self.impl = 2           # 2: fused kernel, bf16-split MFMA (fastest, fp32-accurate); 1: fused, bit-exact f32 MFMA; 0: one kernel per TF op
 
     # ---- copies, weights ---------------------------------------------------------------------------------------------
     def copy(self, *, path_writer: str = '', namespace: str = '', copy_weights: bool = True):

@@ -923,7 +923,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     if (!rc && hipEventCreate(&l->ev_total[0]) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipEventCreate");
     if (!rc && hipEventCreate(&l->ev_total[1]) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipEventCreate");
     if (rc) { gnn_loop_destroy(l); return rc; }
-    l->impl_req = 1;
+    l->impl_req = 2;            // fastest supported path by default; gnn_loop_set_impl(1) selects the bit-exact f32 MFMA
     (void)maxw_s;
     *out = l;
     return GNN_OK;

@@ -154,8 +154,15 @@ int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *
                             float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes);
 int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets, const float *out,
                   const float *sample_weights, double *loss, float *d_out);
-/* selects the implementation: 0 = unfused reference kernels (one kernel per TF op), 1 = fused gather+MLP kernel
- * when the shapes allow it (default), falling back to 0 otherwise.  *used (may be NULL) reports the choice. */
+/* selects the implementation:
+ *   0 = unfused reference kernels (one kernel per TF op), bit-identical to oracle/gnn_oracle.c;
+ *   1 = fused gather + MLP kernel with the dense layers on the f32 MFMA: the same k-ordered fmaf chains, bit-identical
+ *       to the oracle;
+ *   2 = (default) fused kernel with the dense layers on the bf16 MFMA: every fp32 operand is cut into three exact bf16
+ *       pieces and the six leading piece products are accumulated in fp32 (error per product <= 3 * 2^-24, i.e. fp32
+ *       rounding level), activations through v_exp_f32 / v_rcp_f32; results within fp32 rounding noise of 0 / 1
+ *       (tests: 1e-5 against the float64 oracle, the tolerance of BASELINE.json), not bit for bit.
+ * 1 and 2 fall back to 0 when the shapes are not covered.  *used (may be NULL) reports the choice. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);
 /* per-kernel HIP-event timing of the last gnn_loop_run when profiling was enabled:
  * avg_iter_ms = mean duration of the per-iteration kernel(s), total_ms = whole loop on the stream. */
