@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'libgnn_hip.so')
 
 ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 'sigmoid': 5, 'softmax': 6}
 
-EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create',
+EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create', 'gnn_graph_create_from_arcs',
            'gnn_graph_derive', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
@@ -130,6 +130,29 @@ class Graph:
                                       _ip(indptr), _ip(adj_src), _fp(adj_w), _fp(arc_w), _fp(arc_labels),
                                       C.c_int(arc_labels.shape[1]), _fp(nodes), C.c_int(nodes.shape[1]),
                                       mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(device), C.byref(self._h)))
+
+    @classmethod
+    def from_arcs(cls, n_nodes, arc_src, arc_dst, arc_labels, aggregation_mode, nodes, mask, device=0):
+        """gnn_graph_create_from_arcs: device-side COO -> CSR build.  Returns (Graph, indptr, adj_src, adj_w, arc_id, arc_w):
+        the handle and the host mirrors of Adjacency^T / ArcNode^T."""
+        require_device(device)
+        modes = {'sum': 0, 'normalized': 1, 'average': 2}
+        if aggregation_mode not in modes: raise ValueError('ERROR: Unknown aggregation mode')
+        arc_src = np.ascontiguousarray(arc_src, dtype=np.int32)
+        arc_dst = np.ascontiguousarray(arc_dst, dtype=np.int32)
+        arc_labels, nodes = _f32(arc_labels), _f32(nodes)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        e = len(arc_src)
+        if len(arc_dst) != e or arc_labels.shape[0] != e or nodes.shape[0] != n_nodes or len(mask) != n_nodes:
+            raise ValueError('inconsistent array lengths')
+        indptr, adj_src, arc_id = np.zeros(n_nodes + 1, np.int32), np.zeros(e, np.int32), np.zeros(e, np.int32)
+        adj_w, arc_w = np.zeros(e, np.float32), np.zeros(e, np.float32)
+        h = C.c_void_p()
+        _check(lib().gnn_graph_create_from_arcs(C.c_int64(n_nodes), C.c_int64(e), _ip(arc_src), _ip(arc_dst), _fp(arc_labels),
+                                                C.c_int(arc_labels.shape[1]), C.c_int(modes[aggregation_mode]), _fp(nodes), C.c_int(nodes.shape[1]),
+                                                mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(device), C.byref(h), _ip(indptr), _ip(adj_src),
+                                                _fp(adj_w), _ip(arc_id), _fp(arc_w)))
+        return cls(None, None, None, None, None, None, None, None, _handle=h), indptr, adj_src, adj_w, arc_id, arc_w
 
     def dims(self):
         n, r, e, m = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()

@@ -220,6 +220,30 @@ class GraphTensor:
                    sample_weights=g.sample_weights, NodeGraph=g.NodeGraph, Adjacency=cls.COO2SparseTransposedTensor(g.Adjacency),
                    ArcNode=cls.COO2SparseTransposedTensor(g.ArcNode), aggregation_mode=g.aggregation_mode)
 
+    @classmethod
+    def fromArcs(cls, nodes, arcs, targets, problem_based: str = 'n', set_mask=None, output_mask=None, sample_weights=1,
+                 NodeGraph=None, aggregation_mode: str = 'average', device: int = 0):
+        """GraphTensor built on the DEVICE from the arc list (``gnn_graph_create_from_arcs``): same tensors as
+        ``fromGraphObject(GraphObject(...))`` without the host-side sparse matrices (reference graph_class.py:90-121,
+        :365-372), for graphs where that Python would take minutes.  ``arcs`` is [E, 2 + AL] as in GraphObject, used as given
+        (GraphObject sorts and de-duplicates its arcs; pass them that way if the arc order matters to you)."""
+        from GNN import _engine
+        nodes = np.ascontiguousarray(nodes, dtype=np.float32)
+        arcs = np.ascontiguousarray(arcs, dtype=np.float32)
+        n, e = nodes.shape[0], arcs.shape[0]
+        lens = {'n': n, 'a': e, 'g': n}[problem_based]
+        set_mask = np.ones(lens, bool) if set_mask is None else np.asarray(set_mask, bool)
+        output_mask = np.ones(lens, bool) if output_mask is None else np.asarray(output_mask, bool)
+        mask = np.logical_and(set_mask, output_mask) if lens == n else np.ones(n, bool)
+        targets = np.asarray(targets, dtype=np.float32)
+        if np.isscalar(sample_weights): sample_weights = np.full(targets.shape[0], sample_weights, dtype=np.float32)
+        dev, indptr, adj_src, adj_w, arc_id, arc_w = _engine.Graph.from_arcs(n, arcs[:, 0].astype(np.int32), arcs[:, 1].astype(np.int32),
+                                                                              arcs[:, 2:], aggregation_mode, nodes, mask, device)
+        gt = cls(nodes=nodes, arcs=arcs, targets=targets, set_mask=set_mask, output_mask=output_mask, sample_weights=sample_weights,
+                 Adjacency=(indptr, adj_src, adj_w), ArcNode=(indptr, arc_id, arc_w), NodeGraph=NodeGraph, aggregation_mode=aggregation_mode)
+        gt._device_graph = dev
+        return gt
+
     @staticmethod
     def COO2SparseTransposedTensor(coo):
         """Transposed, row-major reordered sparse matrix as a CSR triple (reference graph_class.py:365-372)."""

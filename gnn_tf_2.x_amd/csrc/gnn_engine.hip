@@ -1117,8 +1117,6 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     if (l->edge_expected && !l->edge_mode)
         return gnn_fail(GNN_ERR_STATE, "net_output has the edge-based input width: call gnn_loop_set_edge_readout first");
     HIPCHK(hipSetDevice(l->device));
-    gnn_graph *g = l->g;
-    const int P = l->world;
     hipStream_t st = l->stream;
     const bool fused = l->impl_req >= 1 && gnn_fused_supported(l);
     l->impl_used = fused ? l->impl_req : 0;

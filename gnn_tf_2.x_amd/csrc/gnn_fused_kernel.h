@@ -608,7 +608,7 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
                                                  int KP, int c_aggs)
 {
     constexpr int GB = 16, Ds = 64;
-    const int gl = lane & 15, grp = lane >> 4, gbase = lane & 48;
+    const int gl = lane & 15, grp = lane >> 4;
     // own state rows: 8 x 16 B per lane requested now, written to LDS after the gather (their latency hides behind it)
     v4f own[8];
     {

@@ -66,6 +66,18 @@ int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_rows, int64_t
                      const int32_t *adj_src, const float *adj_w, const float *arc_w, const float *arc_labels,
                      int dim_arc_label, const float *nodes, int dim_node_label, const uint8_t *mask, int device,
                      gnn_graph **out);
+/* Builds the same graph from its arc list on the device (replaces GraphObject.buildArcNode / buildAdiacency and
+ * GraphTensor.COO2SparseTransposedTensor, reference GNN/graph_class.py:90-121, :365-372, for graphs where the host build
+ * would take minutes): arc a goes from arc_src[a] to arc_dst[a] with labels arc_labels[a, :] (ORIGINAL arc order);
+ * aggregation_mode 0 = 'sum', 1 = 'normalized' (1 / number of arcs), 2 = 'average' (1 / in-degree of the destination).
+ * Two stable radix sorts give Adjacency^T (entries of a destination by ascending source) and ArcNode^T (by ascending arc
+ * id).  Single GPU: the handle owns all rows.  The optional outputs (any may be NULL) return the host mirrors:
+ * indptr [n_nodes + 1], adj_src / adj_w [n_arcs] in Adjacency^T order, arc_id / arc_w [n_arcs] in ArcNode^T order. */
+int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const int32_t *arc_src, const int32_t *arc_dst,
+                               const float *arc_labels, int dim_arc_label, int aggregation_mode, const float *nodes,
+                               int dim_node_label, const uint8_t *mask, int device, gnn_graph **out,
+                               int32_t *indptr_out, int32_t *adj_src_out, float *adj_w_out, int32_t *arc_id_out,
+                               float *arc_w_out);
 /* LGNN.update_graph (GNN/LGNN.py:227-260) for node/graph-based layers, on the device:
  * dst.nodes <- [base.nodes | state of `from` (if get_state) | scatter(mask, output of `from`) (if get_output)].
  * `dst` must have been created by gnn_graph_derive(base, extra) with extra = get_state*Ds + get_output*T. */

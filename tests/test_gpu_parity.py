@@ -431,3 +431,43 @@ def test_full_size_properties():
         inp[t, 134] = (s['arc_w'][e0:e1].astype(np.float64) * s['arc_labels_csr'][e0:e1, 0]).sum()
     ref = orc.mlp_forward(inp, st['weights'], st['activations'], True, np.float64)
     assert np.max(np.abs(s1[rows] - ref)) < 1e-5
+
+
+@pytest.mark.parametrize('mode', ['sum', 'normalized', 'average'])
+@pytest.mark.parametrize('sort', [True, False])
+def test_device_graph_build_matches_host_build(mode, sort):
+    """gnn_graph_create_from_arcs (radix sorts + histogram on the GPU) against the host chain buildArcNode / buildAdiacency /
+    COO2SparseTransposedTensor (reference graph_class.py:90-121, :365-372): identical index arrays and weights, and a Loop
+    on either handle gives identical bits."""
+    from GNN.graph_class import GraphObject, GraphTensor
+    rng = np.random.default_rng(5 + sort)
+    n, nl, al = 900, 3, 2
+    arcs = random_arcs(rng, n, 4000, al, sort=sort)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    set_mask = rng.random(n) < 0.8
+    g = orc.make_graph_dict(arcs, nodes, mode)           # host restatement of the reference's matrices, arcs used as given
+    dev = GraphTensor.fromArcs(nodes, arcs, np.zeros((n, 2)), set_mask=set_mask, aggregation_mode=mode)
+    for got, want in zip(dev.Adjacency, g['adjT']):
+        assert np.array_equal(got, want)
+    for got, want in zip(dev.ArcNode, g['arcT']):
+        assert np.array_equal(got, want)
+    if sort:     # GraphObject keeps sorted unique arcs as they are: the two GraphTensors must coincide
+        host = GraphTensor.fromGraphObject(GraphObject(arcs=arcs, nodes=nodes, targets=np.zeros((n, 2)), set_mask=set_mask, aggregation_mode=mode))
+        assert all(np.array_equal(a, b) for a, b in zip(host.Adjacency, dev.Adjacency))
+        assert all(np.array_equal(a, b) for a, b in zip(host.ArcNode, dev.ArcNode))
+    st, ou = make_mlp(rng, al + 2 * (nl + 8), [16, 8], 'tanh', gain=0.6), make_mlp(rng, nl + 8, [2], 'softmax')
+    s0 = (0.1 * rng.standard_normal((n, 8))).astype(np.float32)
+    e = _engine()
+    g['set_mask'] = set_mask
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    res = []
+    for graph in (dev.device_graph(), _device_graph(g)):
+        loop = e.Loop(graph, mst, mou, 8, 20, 0.01)
+        loop.set_impl(1)
+        loop.set_state0(s0)
+        res.append((loop.run(), loop.state(), loop.output()))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    kc, sc, oc = corc.loop_node(g, st, ou, 8, 20, 0.01, s0)
+    assert res[0][0] == kc and np.array_equal(res[0][1], sc) and np.array_equal(res[0][2], oc)
+    with pytest.raises(ValueError):
+        GraphTensor.fromArcs(nodes, arcs, np.zeros((n, 2)), aggregation_mode='mean')     # reference graph_class.py:86
