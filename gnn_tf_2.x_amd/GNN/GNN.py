@@ -179,9 +179,11 @@ class GNNedgeBased(GNNnodeBased):
         k = loop.run(False)
         return k, loop.state(), loop.output()
 
-    def _prepare_loop(self, g: GraphTensor, loop) -> None:
+    def _prepare_loop(self, g: GraphTensor, loop, own_labels: bool = False) -> None:
+        """own_labels: the loop runs on an LGNN-derived graph, which carries its own (widened) arc labels on the device."""
         if not getattr(loop, '_edge_ready', False):
-            loop.set_edge_readout(*g.edge_readout_arrays())
+            entry_dst, arc_labels, mask = g.edge_readout_arrays()
+            loop.set_edge_readout(entry_dst, None if own_labels else arc_labels, mask)
             loop._edge_ready = True
 
 

@@ -103,9 +103,8 @@ class LGNN(BaseClass):
         return it, np.sum(loss), targs, out[-1]
 
     def update_graph(self, g: GraphTensor, state, output) -> GraphTensor:
-        """Host form of the relabelling (reference LGNN.py:227-260); Loop uses the device form instead."""
-        if self.GNNS_TYPE == GNNedgeBased:
-            raise NotImplementedError('edge-based LGNN relabelling (reference LGNN.py:253-254) is not implemented yet')
+        """Host form of the relabelling (reference LGNN.py:227-260); Loop uses the device form instead.  Node/graph-based
+        layers put the scattered output on the node labels, edge-based ones on the arc labels (:253-256)."""
         g = g.copy()
         extra = []
         if self.get_state: extra.append(np.asarray(state, dtype=np.float32))
@@ -113,37 +112,58 @@ class LGNN(BaseClass):
             mask = g.loop_mask()
             scattered = np.zeros((len(mask), output.shape[1]), dtype=np.float32)
             scattered[np.nonzero(mask)[0]] = output
-            extra.append(scattered)
+            if self.GNNS_TYPE == GNNedgeBased:
+                g.arcs = np.concatenate([g.arcs, scattered], axis=1)
+            else:
+                extra.append(scattered)
         g.nodes = np.concatenate([g.nodes] + extra, axis=1)
+        g._device_graph = None
         return g
 
     def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
         """(K list, last state, outs list) as reference LGNN.py:263-290.  ``state0``: optional list of injected initial
         states, one per layer."""
-        if self.GNNS_TYPE == GNNedgeBased:
-            raise NotImplementedError('edge-based LGNN is not implemented on the MI355X engine yet')
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
         graph_based = self.GNNS_TYPE == GNNgraphBased
+        edge_based = self.GNNS_TYPE == GNNedgeBased
+        if edge_based and training:
+            raise NotImplementedError('Loop(training=True) of an edge-based LGNN is not implemented on the MI355X engine yet')
         if graph_based:
             if g.NodeGraph is None: raise ValueError('WRONG GNN. NodeGraph is None: GNN is graph-based, while problem is non graph-based.')
             if not g.loop_mask().all(): raise ValueError('graph-based GNN needs set_mask and output_mask all True')
         state0 = state0 or [None] * self.LAYERS
         base = g.device_graph(self.gnns[0].device)
+        if edge_based and not g.__dict__.get('_arc_order_set'):
+            base.set_arc_order(g.ArcNode[1], g.arcs[:, 2:])        # what the arc side of the relabelling needs
+            g._arc_order_set = True
         current = base
         derived = g.__dict__.setdefault('_lgnn_graphs', {})
         K, outs = [], []
         loop = None
         for idx, gnn in enumerate(self.gnns):
-            k, loop = gnn._run(current, training, state0[idx])
+            if edge_based:
+                loop = gnn._device_loop(current)
+                gnn._prepare_loop(g, loop, own_labels=current is not base)
+                if gnn.state_vect_dim > 0: loop.set_state0(state0[idx], gnn.seed)
+                k = loop.run(False)
+            else:
+                k, loop = gnn._run(current, training, state0[idx])
             K.append(k)
             last = idx == self.LAYERS - 1
             outs.append(loop.readout(*g.nodegraph_csr()) if graph_based else loop.output())
             if not last:
-                # relabel from the ORIGINAL graph (reference LGNN.py:287): [nodes | state? | scattered output?]
-                extra = self.get_state * loop.Ds + self.get_output * loop.T
-                nxt = derived.get(extra)
-                if nxt is None:
-                    nxt = derived[extra] = base.derive(extra)
+                # relabel from the ORIGINAL graph (reference LGNN.py:287): nodes [nodes | state? | scattered output?], or, for
+                # edge-based layers, nodes [nodes | state?] and arcs [arc labels | scattered output?]
+                if edge_based:
+                    key = ('a', self.get_state * loop.Ds, self.get_output * loop.T)
+                    nxt = derived.get(key)
+                    if nxt is None:
+                        nxt = derived[key] = base.derive_edge(key[1], key[2])
+                else:
+                    key = self.get_state * loop.Ds + self.get_output * loop.T
+                    nxt = derived.get(key)
+                    if nxt is None:
+                        nxt = derived[key] = base.derive(key)
                 nxt.update_labels(base, loop, self.get_state, self.get_output)
                 current = nxt
         return K, loop.state(), outs
@@ -161,7 +181,7 @@ class LGNN(BaseClass):
             for idx, gnn in enumerate(self.gnns):
                 if verbose in [1, 3]: print(f'\n\n------------------- GNN{idx} -------------------\n')
                 gnn.train(gTr1, epochs, gVa1, update_freq, max_fails, observed_metric, policy, mean=mean, verbose=verbose)
-                node_loop = lambda g: GNNnodeBased.Loop(gnn, g)
+                node_loop = (lambda g: gnn.Loop(g)) if self.GNNS_TYPE == GNNedgeBased else (lambda g: GNNnodeBased.Loop(gnn, g))
                 gTr1 = [self.update_graph(g, *node_loop(gt)[1:]) for g, gt in zip(gTr0, gTr1)]
                 if gVa0: gVa1 = [self.update_graph(g, *node_loop(gt)[1:]) for g, gt in zip(gVa0, gVa1)]
             return
@@ -176,7 +196,8 @@ class LGNN(BaseClass):
         ``state0`` / ``masks_*``: optional per-layer lists (tests inject them)."""
         from GNN import losses, _engine
         if self.GNNS_TYPE == GNNedgeBased:
-            raise NotImplementedError('edge-based LGNN is not implemented on the MI355X engine yet')
+            raise NotImplementedError("joint training ('parallel' / 'residual') of an edge-based LGNN is not implemented on the MI355X "
+                                      "engine yet (training_mode='serial' is)")
         if self.training_mode not in ('parallel', 'residual'):
             raise ValueError("training_step is the joint step of training_mode 'parallel' / 'residual'")
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)

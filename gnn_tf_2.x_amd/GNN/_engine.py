@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libgnn_hip.so')
 ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 'sigmoid': 5, 'softmax': 6}
 
 EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create', 'gnn_graph_create_from_arcs',
-           'gnn_graph_derive', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
+           'gnn_graph_derive', 'gnn_graph_derive_edge', 'gnn_graph_set_arc_order', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loss_grad',
@@ -165,6 +165,15 @@ class Graph:
         _check(lib().gnn_graph_derive(self._h, C.c_int(extra), C.byref(h)))
         return Graph(None, None, None, None, None, None, None, None, _handle=h)
 
+    def derive_edge(self, extra_nodes: int, extra_arcs: int) -> 'Graph':
+        h = C.c_void_p()
+        _check(lib().gnn_graph_derive_edge(self._h, C.c_int(extra_nodes), C.c_int(extra_arcs), C.byref(h)))
+        return Graph(None, None, None, None, None, None, None, None, _handle=h)
+
+    def set_arc_order(self, arc_id, arc_labels_orig) -> None:
+        arc_id = np.ascontiguousarray(arc_id, dtype=np.int32)
+        _check(lib().gnn_graph_set_arc_order(self._h, _ip(arc_id), _fp(_f32(arc_labels_orig))))
+
     def update_labels(self, base: 'Graph', loop: 'Loop', get_state: bool, get_output: bool) -> None:
         _check(lib().gnn_graph_update_labels(self._h, base._h, loop._h, C.c_int(bool(get_state)), C.c_int(bool(get_output))))
 
@@ -300,11 +309,12 @@ class Loop:
     def set_edge_readout(self, entry_dst, arc_labels, arc_mask):
         """Switch to the per-arc readout of GNNedgeBased (reference GNN.py:289-302)."""
         entry_dst = np.ascontiguousarray(entry_dst, dtype=np.int32)
-        arc_labels = _f32(arc_labels)
+        arc_labels = _f32(arc_labels) if arc_labels is not None else None      # None: the (derived) graph owns its arc labels
         arc_mask = np.ascontiguousarray(arc_mask, dtype=np.uint8)
-        if not (len(entry_dst) == len(arc_mask) == arc_labels.shape[0]):
+        if not (len(entry_dst) == len(arc_mask)) or (arc_labels is not None and arc_labels.shape[0] != len(arc_mask)):
             raise ValueError('entry_dst, arc_labels and arc_mask must have one row per arc')
-        _check(lib().gnn_loop_set_edge_readout(self._h, _ip(entry_dst), _fp(arc_labels), arc_mask.ctypes.data_as(C.POINTER(C.c_uint8))))
+        _check(lib().gnn_loop_set_edge_readout(self._h, _ip(entry_dst), _fp(arc_labels) if arc_labels is not None else None,
+                                               arc_mask.ctypes.data_as(C.POINTER(C.c_uint8))))
         self.n_masked = int(arc_mask.sum())
 
     def train_step(self, net_state: 'Mlp', net_output: 'Mlp', src_csr, targets, sample_weights, loss_kind: int, ng_csr=None,

@@ -123,7 +123,7 @@ extern "C" int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const
 
     gnn_graph *g = new gnn_graph();
     g->device = device; g->N = N; g->row_begin = 0; g->n_rows = N; g->E = E;
-    g->NL = dim_node_label; g->AL = AL; g->base_NL = dim_node_label;
+    g->NL = dim_node_label; g->AL = AL; g->base_NL = dim_node_label; g->base_AL = AL;
     g->sh = new gnn_graph_shared();
     gnn_graph_shared *sh = g->sh;
     auto fail = [&](int code) { gnn_graph_destroy(g); return code; };

@@ -99,6 +99,10 @@ struct gnn_graph_shared {
     // pass; built on first use by gnn_train.hip when the caller passes no by-source arrays
     int32_t *src_indptr = nullptr, *src_dst = nullptr;
     float *src_w = nullptr;
+    // arc-side LGNN relabelling (LGNN.py:253-254): arc id of every ArcNode^T entry and the arc labels in ORIGINAL arc order
+    // (gnn_graph_set_arc_order)
+    int32_t *arc_id = nullptr;
+    float *arc_labels_orig = nullptr;
 };
 
 struct gnn_graph {
@@ -108,7 +112,12 @@ struct gnn_graph {
     gnn_graph_shared *sh = nullptr;
     float *nodes = nullptr;   // [N, NL]
     int base_NL = 0;          // derived graphs: label width of the base graph
+    // derived graphs of an edge-based LGNN own widened arc labels: ArcNode^T order (aggregation) and original order (readout)
+    float *arc_labels_own = nullptr, *arc_labels_orig_own = nullptr;
+    int base_AL = 0;
 };
+
+inline const float *gnn_graph_arc_labels(const gnn_graph *g) { return g->arc_labels_own ? g->arc_labels_own : g->sh->arc_labels; }
 
 struct gnn_mlp {
     int device = 0;

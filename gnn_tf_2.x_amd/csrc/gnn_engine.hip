@@ -432,6 +432,36 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
+// arc side of LGNN.update_graph (LGNN.py:253-254), original arc order: dst[p] = [base labels of arc p | 0 ...]; the output rows
+// are then scattered over the masked positions by k_arc_scatter
+__global__ void k_arc_base(int64_t E, int ALb, const float *__restrict__ base, int ALd, float *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * ALd) return;
+    const int64_t p = t / ALd;
+    const int c = (int)(t - p * ALd);
+    dst[t] = c < ALb ? base[p * ALb + c] : 0.0f;
+}
+
+__global__ void k_arc_scatter(int64_t M, int T, const int32_t *__restrict__ rows, const float *__restrict__ out, int ALb, int ALd, float *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * T) return;
+    const int64_t m = t / T;
+    const int c = (int)(t - m * T);
+    dst[(int64_t)rows[m] * ALd + ALb + c] = out[t];
+}
+
+// ArcNode^T order: entry q carries the labels of arc arc_id[q]
+__global__ void k_arc_permute(int64_t E, int AL, const int32_t *__restrict__ arc_id, const float *__restrict__ orig, float *__restrict__ csr)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * AL) return;
+    const int64_t q = t / AL;
+    const int c = (int)(t - q * AL);
+    csr[t] = orig[(int64_t)arc_id[q] * AL + c];
+}
+
 __global__ void k_randn(int64_t count, int64_t offset, uint64_t seed, float stddev, float *out)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -510,7 +540,7 @@ int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state,
     const gnn_graph *g = l->g;
     const int64_t tot = l->n_edge_masked * l->ou->dims[0];
     hipLaunchKernelGGL(k_feats_edge, cdiv(tot, 256), 256, 0, st, l->n_edge_masked, l->edge_rows, l->edge_dst, g->sh->adj_src, state, state,
-                       l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, l->edge_labels, g->AL, feats);
+                       l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, g->arc_labels_orig_own ? g->arc_labels_orig_own : l->edge_labels, g->AL, feats);
     HIPCHK(hipGetLastError());
     return GNN_OK;
 }
@@ -560,6 +590,7 @@ static void graph_release_shared(gnn_graph_shared *sh)
     (void)hipFree(sh->indptr); (void)hipFree(sh->adj_src); (void)hipFree(sh->masked_rows);
     (void)hipFree(sh->adj_w); (void)hipFree(sh->arc_w); (void)hipFree(sh->arc_labels); (void)hipFree(sh->mask);
     (void)hipFree(sh->src_indptr); (void)hipFree(sh->src_dst); (void)hipFree(sh->src_w);
+    (void)hipFree(sh->arc_id); (void)hipFree(sh->arc_labels_orig);
     delete sh;
 }
 
@@ -591,7 +622,7 @@ extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_ro
     HIPCHK(hipSetDevice(device));
     gnn_graph *g = new gnn_graph();
     g->device = device; g->N = n_nodes; g->row_begin = row_begin; g->n_rows = n_rows; g->E = n_arcs;
-    g->NL = dim_node_label; g->AL = dim_arc_label; g->base_NL = dim_node_label;
+    g->NL = dim_node_label; g->AL = dim_arc_label; g->base_NL = dim_node_label; g->base_AL = dim_arc_label;
     g->sh = new gnn_graph_shared();
     g->sh->max_degree = maxdeg;
     // masked_rows holds [n_masked] owned-row indices with mask set, followed by [n_rows] exclusive positions
@@ -630,6 +661,42 @@ extern "C" int gnn_graph_derive(const gnn_graph *base, int extra, gnn_graph **ou
     return GNN_OK;
 }
 
+extern "C" int gnn_graph_set_arc_order(gnn_graph *g, const int32_t *arc_id, const float *arc_labels_orig)
+{
+    ARGCHK(g && (g->E == 0 || (arc_id && (arc_labels_orig || g->AL == 0))), "bad arguments");
+    ARGCHK(g->NL == g->base_NL && !g->arc_labels_own, "set the arc order on the original (underived) graph");
+    HIPCHK(hipSetDevice(g->device));
+    std::vector<uint8_t> seen((size_t)g->E, 0);
+    for (int64_t q = 0; q < g->E; ++q) {
+        ARGCHK(arc_id[q] >= 0 && arc_id[q] < g->E && !seen[arc_id[q]], "arc_id is not a permutation of the arcs at entry %lld", (long long)q);
+        seen[arc_id[q]] = 1;
+    }
+    (void)hipFree(g->sh->arc_id); (void)hipFree(g->sh->arc_labels_orig);
+    g->sh->arc_id = nullptr; g->sh->arc_labels_orig = nullptr;
+    int rc = dev_upload(&g->sh->arc_id, arc_id, (size_t)g->E);
+    if (!rc) rc = dev_upload(&g->sh->arc_labels_orig, arc_labels_orig, (size_t)g->E * g->AL);
+    return rc;
+}
+
+extern "C" int gnn_graph_derive_edge(const gnn_graph *base, int extra_nodes, int extra_arcs, gnn_graph **out)
+{
+    ARGCHK(base && out && extra_nodes >= 0 && extra_arcs >= 0, "bad arguments");
+    ARGCHK(base->sh->arc_id, "call gnn_graph_set_arc_order on the base graph first");
+    int rc = gnn_graph_derive(base, extra_nodes, out);
+    if (rc) return rc;
+    gnn_graph *g = *out;
+    *out = nullptr;
+    g->AL = base->base_AL + extra_arcs;
+    g->arc_labels_own = g->arc_labels_orig_own = nullptr;
+    rc = dev_alloc(&g->arc_labels_own, (size_t)g->E * g->AL);
+    if (!rc) rc = dev_alloc(&g->arc_labels_orig_own, (size_t)g->E * g->AL);
+    if (rc) { gnn_graph_destroy(g); return rc; }
+    HIPCHK(hipMemset(g->arc_labels_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)));
+    HIPCHK(hipMemset(g->arc_labels_orig_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)));
+    *out = g;
+    return GNN_OK;
+}
+
 extern "C" int gnn_graph_get_nodes(const gnn_graph *g, float *nodes_out)
 {
     ARGCHK(g && nodes_out, "bad arguments");
@@ -653,6 +720,7 @@ extern "C" int gnn_graph_dims(const gnn_graph *g, int64_t *n_nodes, int64_t *n_r
 
 extern "C" int gnn_graph_destroy(gnn_graph *g)
 {
+    if (g) { (void)hipFree(g->arc_labels_own); (void)hipFree(g->arc_labels_orig_own); }
     if (!g) return GNN_OK;
     (void)hipSetDevice(g->device);
     (void)hipFree(g->nodes);
@@ -1043,7 +1111,7 @@ static int loop_enqueue(gnn_loop *l, bool fused)
     // loop-invariant aggregates (GNN.py:259, :263)
     if (!fused) {
         const int c_nodes = l->Ds, c_aggn = l->Ds + l->NLc + l->Ds, c_agga = c_aggn + l->NLc;
-        rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL, l->inp + c_agga, l->in_s, nullptr, 1);
+        rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, l->inp + c_agga, l->in_s, nullptr, 1);
         if (rc) return rc;
         if (l->D) {
             rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, l->inp + c_aggn, l->in_s, nullptr, 1);
@@ -1079,7 +1147,7 @@ static int loop_enqueue(gnn_loop *l, bool fused)
             const int we = l->ou->dims[0];
             const int64_t tot = l->n_edge_masked * we;
             hipLaunchKernelGGL(k_feats_edge, cdiv(tot, 256), 256, 0, st, l->n_edge_masked, l->edge_rows, l->edge_dst, g->sh->adj_src, l->state[0],
-                               l->state[1], l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, l->edge_labels, g->AL, l->feats);
+                               l->state[1], l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, g->arc_labels_orig_own ? g->arc_labels_orig_own : l->edge_labels, g->AL, l->feats);
             HIPCHK(hipGetLastError());
             rc = launch_mlp(st, l->ou, l->n_edge_masked, l->feats, we, l->out, l->T, l->otmp[0], l->otmp[1], nullptr, 1);
             if (rc) return rc;
@@ -1176,7 +1244,7 @@ extern "C" int gnn_loop_get_output(const gnn_loop *l, float *out, int64_t *n_mas
 
 extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, const float *arc_labels, const uint8_t *arc_mask)
 {
-    ARGCHK(l && (l->g->E == 0 || (entry_dst && arc_mask && (arc_labels || l->g->AL == 0))), "bad arguments");
+    ARGCHK(l && (l->g->E == 0 || (entry_dst && arc_mask && (arc_labels || l->g->AL == 0 || l->g->arc_labels_orig_own))), "bad arguments");
     ARGCHK(l->edge_expected, "net_output input width %d is not the edge-based 2 (NL + D) + AL", l->ou->dims[0]);
     ARGCHK(l->world == 1 && l->g->n_rows == l->g->N, "the edge-based readout is single-GPU only");
     const gnn_graph *g = l->g;
@@ -1195,7 +1263,7 @@ extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, 
     for (int i = 1; i <= l->ou->n_layers; ++i) maxw_o = std::max(maxw_o, l->ou->dims[i]);
     int rc = dev_upload(&l->edge_dst, entry_dst, (size_t)g->E);
     if (!rc) rc = dev_upload(&l->edge_rows, rows.data(), rows.size());
-    if (!rc) rc = dev_upload(&l->edge_labels, arc_labels, (size_t)g->E * g->AL);
+    if (!rc && !g->arc_labels_orig_own) rc = dev_upload(&l->edge_labels, arc_labels, (size_t)g->E * g->AL);   // derived graphs own theirs
     if (!rc) rc = dev_alloc(&l->feats, rows.size() * (size_t)l->ou->dims[0]);
     if (!rc) rc = dev_alloc(&l->out, rows.size() * (size_t)l->T);
     for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], rows.size() * (size_t)maxw_o);
@@ -1249,14 +1317,29 @@ extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, co
     if (!from->ran) return gnn_fail(GNN_ERR_STATE, "the source loop has not run");
     ARGCHK(from->world == 1, "LGNN relabelling of sharded graphs is not supported");
     ARGCHK(from->g->sh == base->sh, "the source loop ran on an unrelated graph");
-    const int extra = (get_state ? from->Ds : 0) + (get_output ? from->T : 0);
+    // edge-based layers put the output on the ARC labels (LGNN.py:253-254), node/graph-based ones on the node labels (:256)
+    const bool arc_side = from->edge_mode;
+    const int out_nodes = (get_output && !arc_side) ? from->T : 0, out_arcs = (get_output && arc_side) ? from->T : 0;
+    const int extra = (get_state ? from->Ds : 0) + out_nodes;
     ARGCHK(dst->NL == base->base_NL + extra, "dst label width %d != %d + %d", dst->NL, base->base_NL, extra);
     HIPCHK(hipSetDevice(dst->device));
     // base labels are the first base_NL columns of base->nodes only when base is not itself derived
     ARGCHK(base->NL == base->base_NL, "base must be the original (underived) graph (LGNN.py:287)");
     const int64_t tot = dst->N * dst->NL;
     hipLaunchKernelGGL(k_relabel, cdiv(tot, 256), 256, 0, from->stream, dst->N, base->NL, base->nodes, from->Ds, from->state[0], from->state[1],
-                       from->kfinal_dev, get_state, from->T, from->out, base->sh->mask, graph_mask_pos(base), get_output, dst->nodes, dst->NL);
+                       from->kfinal_dev, get_state, from->T, from->out, base->sh->mask, graph_mask_pos(base), out_nodes ? 1 : 0, dst->nodes, dst->NL);
+    if (arc_side) {
+        ARGCHK(dst->arc_labels_own && dst->arc_labels_orig_own && base->sh->arc_id, "dst must come from gnn_graph_derive_edge");
+        ARGCHK(dst->AL == base->base_AL + out_arcs, "dst arc label width %d != %d + %d", dst->AL, base->base_AL, out_arcs);
+        const int64_t E = dst->E;
+        if (E && dst->AL) {
+            hipLaunchKernelGGL(k_arc_base, cdiv(E * dst->AL, 256), 256, 0, from->stream, E, base->base_AL, base->sh->arc_labels_orig, dst->AL, dst->arc_labels_orig_own);
+            if (out_arcs && from->n_edge_masked)
+                hipLaunchKernelGGL(k_arc_scatter, cdiv(from->n_edge_masked * from->T, 256), 256, 0, from->stream, from->n_edge_masked, from->T, from->edge_rows,
+                                   from->out, base->base_AL, dst->AL, dst->arc_labels_orig_own);
+            hipLaunchKernelGGL(k_arc_permute, cdiv(E * dst->AL, 256), 256, 0, from->stream, E, dst->AL, base->sh->arc_id, dst->arc_labels_orig_own, dst->arc_labels_own);
+        }
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(from->stream));
     return GNN_OK;

@@ -178,7 +178,7 @@ int gnn_fused_prepare(gnn_loop *l)
     if (IW == 0) return GNN_OK;
     // [nodes | Adjacency^T . nodes | ArcNode^T . arc labels]  (GNN.py:263, :259); recomputed per run: labels may have
     // been rewritten by gnn_graph_update_labels
-    int rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL,
+    int rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL,
                              l->inv + 2 * l->NLc, IW, nullptr, 1);
     if (rc) return rc;
     if (l->NLc) {

@@ -586,7 +586,7 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     if ((rc = buf.get(&tmpl, (size_t)N * in_s))) return rc;
     HIPCHK(hipMemsetAsync(tmpl, 0, sizeof(float) * (size_t)N * in_s, st));
     const int c_nodes = Ds, c_aggs = Ds + NLc, c_aggn = c_aggs + Ds, c_agga = c_aggn + NLc;
-    if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, g->sh->arc_labels, g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
+    if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
     if (l->D) {
         if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, tmpl + c_aggn, in_s, nullptr, 1))) return rc;
         if (N) HIPCHK(hipMemcpy2DAsync(tmpl + c_nodes, sizeof(float) * in_s, g->nodes, sizeof(float) * g->NL, sizeof(float) * g->NL, (size_t)N, hipMemcpyDeviceToDevice, st));

@@ -83,6 +83,14 @@ int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const int32_t *a
  * `dst` must have been created by gnn_graph_derive(base, extra) with extra = get_state*Ds + get_output*T. */
 int gnn_graph_derive(const gnn_graph *base, int extra_node_label_dims, gnn_graph **out);
 int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output);
+/* Edge-based LGNN (reference GNN/LGNN.py:253-254: the output of an edge-based layer widens the ARC labels, its state the
+ * node labels).  gnn_graph_set_arc_order gives the original graph what the arc side needs: arc_id [n_arcs] = arc of every
+ * ArcNode^T entry (the permutation COO2SparseTransposedTensor applied) and the arc labels in ORIGINAL arc order.
+ * gnn_graph_derive_edge is gnn_graph_derive with extra arc-label columns; gnn_graph_update_labels then fills node labels
+ * [base | state?] and arc labels [base | scatter(out) over the arc mask?] when `from` is an edge-based loop, and loops
+ * created on the derived graph read their per-arc readout labels from it (gnn_loop_set_edge_readout: arc_labels = NULL). */
+int gnn_graph_set_arc_order(gnn_graph *g, const int32_t *arc_id, const float *arc_labels_orig);
+int gnn_graph_derive_edge(const gnn_graph *base, int extra_nodes, int extra_arcs, gnn_graph **out);
 int gnn_graph_get_nodes(const gnn_graph *g, float *nodes_out /* [N, dim_node_label] */);
 int gnn_graph_dims(const gnn_graph *g, int64_t *n_nodes, int64_t *n_rows, int64_t *n_arcs, int *dim_node_label,
                    int *dim_arc_label, int64_t *n_masked);

@@ -316,6 +316,37 @@ def update_graph(g: dict, state: np.ndarray, output: np.ndarray, get_state: bool
     return new
 
 
+def loop_edge(g: dict, net_state, net_output, state_vect_dim, max_iteration, threshold, state0=None, dtype=np.float32):
+    """GNNedgeBased.Loop.  Follows GNN/GNN.py:286-302 on top of :251-280: the node-based state loop, then net_output on the
+    per-arc rows of edge_features (set_mask / output_mask are over the ARCS)."""
+    n = np.asarray(g['nodes']).shape[0]
+    node_side = dict(g, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool))
+    ds = state_vect_dim if state_vect_dim else np.asarray(g['nodes']).shape[1]
+    wn = ds + (np.asarray(g['nodes']).shape[1] if state_vect_dim else 0)
+    dummy = dict(weights=[np.zeros((wn, 1), dtype), np.zeros(1, dtype)], activations=['linear'], batch_normalization=False)
+    k, state, _ = loop_node(node_side, net_state, dummy, state_vect_dim, max_iteration, threshold, state0, dtype)
+    feats = edge_features(g, state, state_vect_dim, dtype)
+    out = mlp_forward(feats, net_output['weights'], net_output['activations'], net_output['batch_normalization'], dtype)
+    return k, state, out
+
+
+def update_graph_edge(g: dict, state: np.ndarray, output: np.ndarray, get_state: bool, get_output: bool, dtype=np.float32):
+    """LGNN.update_graph for EDGE-based layers.  Follows GNN/LGNN.py:227-260 with :253-254: nodes <- [g.nodes | state?],
+    arcs <- [g.arcs | scatter_nd(where(arc mask), output)?]; always from the ORIGINAL graph (:287).  The sparse operands
+    are unchanged (same arcs), only the label columns grow."""
+    new = dict(g)
+    nodes = np.asarray(g['nodes'], dtype=dtype)
+    if get_state:
+        nodes = np.concatenate([nodes, np.asarray(state, dtype=dtype)], axis=1)
+    new['nodes'] = nodes
+    if get_output:
+        mask = np.logical_and(g['set_mask'], g['output_mask'])
+        scat = np.zeros((len(mask), output.shape[1]), dtype=dtype)
+        scat[np.nonzero(mask)[0]] = output
+        new['arcs'] = np.concatenate([np.asarray(g['arcs'], dtype=dtype), scat], axis=1)
+    return new
+
+
 def lgnn_loop(g: dict, gnns: list[dict], get_state: bool, get_output: bool, graph_based: bool, state0s=None,
               dtype=np.float32):
     """LGNN.Loop.  Follows GNN/LGNN.py:263-290.

@@ -471,3 +471,52 @@ def test_device_graph_build_matches_host_build(mode, sort):
     assert res[0][0] == kc and np.array_equal(res[0][1], sc) and np.array_equal(res[0][2], oc)
     with pytest.raises(ValueError):
         GraphTensor.fromArcs(nodes, arcs, np.zeros((n, 2)), aggregation_mode='mean')     # reference graph_class.py:86
+
+
+@pytest.mark.parametrize('get_state,get_output', [(True, True), (False, True), (True, False)])
+def test_edge_based_lgnn_stack_on_device(get_state, get_output):
+    """LGNN of GNNedgeBased layers (reference LGNN.py:253-254): the output of a layer widens the ARC labels (scattered through
+    the arc mask, original arc order), its state the node labels; relabelling on the device (gnn_graph_derive_edge +
+    gnn_graph_update_labels), against the C oracle per layer chained by the reference's rule."""
+    from GNN.GNN import GNNedgeBased
+    from GNN.LGNN import LGNN
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(77)
+    n, nl, al, d, t, layers = 250, 3, 2, 6, 2, 3
+    arcs = random_arcs(rng, n, 700, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    e = len(arcs)
+    set_mask, output_mask = rng.random(e) < 0.8, rng.random(e) < 0.75
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=np.zeros((int(output_mask.sum()), t)), problem_based='a', set_mask=set_mask, output_mask=output_mask)
+    gd = orc.make_graph_dict(arcs, nodes, 'average')
+    gd['set_mask'], gd['output_mask'] = set_mask, output_mask
+    gnns, models = [], []
+    for layer in range(layers):
+        ins, ls = orc.get_inout_dims('state', nl, al, t, 'a', d, [12], layer=layer, get_state=get_state, get_output=get_output)
+        ino, lo = orc.get_inout_dims('output', nl, al, t, 'a', d, None, layer=layer, get_state=get_state, get_output=get_output)
+        st, ou = make_mlp(rng, ins, ls, 'tanh', gain=0.5), make_mlp(rng, ino, lo, 'softmax')
+        gnns.append(dict(net_state=st, net_output=ou))
+        models.append(_models(st, ou, d, 12, 0.01, GNNedgeBased))
+    s0s = [(0.1 * rng.standard_normal((n, d))).astype(np.float32) for _ in range(layers)]
+    lgnn = LGNN(models, get_state, get_output, None, None, None, 'c')
+    K, state, outs = lgnn.Loop(go, state0=s0s)
+    gtmp, Kc = dict(gd), []
+    for gnn, s0, got in zip(gnns, s0s, outs):
+        nn_, al_ = np.asarray(gtmp['nodes']).shape[1], np.asarray(gtmp['arcs']).shape[1] - 2
+        assert gnn['net_state']['weights'][0].shape[0] == al_ + 2 * (nn_ + d)       # get_inout_dims agrees with the relabelled widths
+        node_side = dict(gtmp, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool))
+        kc, sc, _ = corc.loop_node(node_side, gnn['net_state'], make_mlp(rng, nn_ + d, [1], 'linear'), d, 12, 0.01, s0, want_out=False)
+        oc = corc.mlp_forward(orc.edge_features(gtmp, sc, d), gnn['net_output']['weights'], gnn['net_output']['activations'], True)
+        Kc.append(kc)
+        assert got.shape == oc.shape == (int((set_mask & output_mask).sum()), t) and np.array_equal(got, oc)
+        gtmp = orc.update_graph_edge(gd, sc, oc, get_state, get_output)
+    assert K == Kc and np.array_equal(state, sc)
+    # float64 restatement of the same chain
+    g64 = dict(gd)
+    for gnn, s0 in zip(gnns, s0s):
+        k64, s64, o64 = orc.loop_edge(g64, gnn['net_state'], gnn['net_output'], d, 12, 0.01, s0, np.float64)
+        g64 = orc.update_graph_edge(gd, s64, o64, get_state, get_output, np.float64)
+    assert np.max(np.abs(outs[-1] - o64)) < 1e-5
+    # host form of update_graph agrees with the oracle's
+    upd = lgnn.update_graph(__import__('GNN.graph_class', fromlist=['GraphTensor']).GraphTensor.fromGraphObject(go), sc, oc)
+    assert np.array_equal(upd.nodes, gtmp['nodes']) and np.array_equal(upd.arcs, gtmp['arcs'])
