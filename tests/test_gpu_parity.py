@@ -146,6 +146,38 @@ def test_loop_edge_cases(impl):
     assert k == kc and np.array_equal(s, sc) and np.array_equal(o, oc)
 
 
+def test_loop_edge_cases_split_arithmetic():
+    """The same edge cases on the default path (impl 2): iteration counts identical, values within fp32 rounding noise."""
+    rng = np.random.default_rng(5)
+    g, st, ou, s0 = _case(rng, n=257, d=4, gain=0.7)              # partial last tile (257 = 8 x 32 + 1)
+    zero = dict(st, weights=[np.zeros_like(w) for w in st['weights'][:-4]] + [np.ones(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32), np.ones(4, np.float32)])
+    k, s, _ = _run_hip(g, zero, ou, 4, 30, 0.01, s0, 2)
+    assert k == 2 and np.all(s == 0)
+    for max_it, thr in ((9, 0.0), (0, 0.01), (30, 0.05)):
+        k, s, o = _run_hip(g, st, ou, 4, max_it, thr, s0, 2)
+        kc, sc, oc = corc.loop_node(g, st, ou, 4, max_it, thr, s0)
+        assert k == kc and np.max(np.abs(s - sc)) < 2e-6 and np.max(np.abs(o - oc)) < 2e-6, (max_it, thr)
+    arcs = np.array([[0, 1, .5], [1, 0, .5]], dtype=np.float32)
+    st1, ou1 = make_mlp(rng, 1 + 2 * 2, [2], 'linear'), make_mlp(rng, 2, [2], 'softmax')
+    g1 = orc.make_graph_dict(arcs, np.ones((3, 2), np.float32))
+    assert _run_hip(g1, st1, ou1, 0, 5, 0.01, None, 2)[0] == 0
+    g2 = orc.make_graph_dict(arcs, rng.random((3, 2)).astype(np.float32))
+    g2['set_mask'] = np.zeros(3, bool)
+    k, s, o = _run_hip(g2, st1, ou1, 0, 5, 0.01, None, 2)
+    kc, sc, _ = corc.loop_node(g2, st1, ou1, 0, 5, 0.01, None, want_out=False)
+    assert k == kc and np.max(np.abs(s - sc)) < 2e-6 and o.shape == (0, 2)
+    g3 = orc.make_graph_dict(np.zeros((0, 3), np.float32), rng.random((5, 2)).astype(np.float32))
+    k, s, o = _run_hip(g3, st1, ou1, 0, 4, 0.01, None, 2)
+    kc, sc, oc = corc.loop_node(g3, st1, ou1, 0, 4, 0.01, None)
+    assert k == kc and np.max(np.abs(s - sc)) < 2e-6 and np.max(np.abs(o - oc)) < 2e-6
+    # large magnitudes: the piece split is exact for any finite fp32 value (no overflow of the remainders)
+    g4, st4, ou4, s04 = _case(rng, n=100, d=8, hidden=(16,), act='relu', gain=0.5)
+    big = dict(st4, weights=[w * (64.0 if i == 0 else 1.0 / 64.0 if i == 2 else 1.0) for i, w in enumerate(st4['weights'])])
+    k, s, o = _run_hip(g4, big, ou4, 8, 10, 0.01, s04, 2)
+    kc, sc, oc = corc.loop_node(g4, big, ou4, 8, 10, 0.01, s04)
+    assert k == kc and np.max(np.abs(s - sc)) < 5e-6 * max(1.0, float(np.max(np.abs(sc))))
+
+
 def test_iteration_count_tracks_threshold():
     """k is decided on the device by the fused '>' test; sweep thresholds so that k changes and must track the oracle."""
     rng = np.random.default_rng(8)
