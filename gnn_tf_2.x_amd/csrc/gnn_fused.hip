@@ -241,7 +241,9 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         HIPCHK(hipGetDeviceProperties(&prop, l->device));
         n_cu = std::max(1, prop.multiProcessorCount);
     }
-    const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, (n_tiles + GNN_FUSED_WAVES - 1) / GNN_FUSED_WAVES);
+    // one workgroup per CU; small graphs spread their tiles over as many CUs as they have tiles (a tile alone on a CU runs
+    // faster than eight sharing its L1 / LDS / SIMDs; the waves without a tile leave at once)
+    const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, n_tiles);
     a.tile_ctr = l->tile_ctr + k;
     static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : 0;   // tuning experiments
     a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_env : 0;   // only when every wave has several tiles to run

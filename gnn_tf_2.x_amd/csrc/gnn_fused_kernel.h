@@ -490,13 +490,27 @@ __device__ __forceinline__ int label_col(int c, int Ds, int NLc)
     return c < NLc ? Ds + c : (c < 2 * NLc ? 2 * Ds + NLc + (c - NLc) : 2 * Ds + 2 * NLc + (c - 2 * NLc));
 }
 
+// (row, column) of the flat index lane, lane + 64, lane + 128, ... of a [rows, width] block: one division per tile instead
+// of one per element (the generic paths are latency chains of small graphs; an integer division is ~40 instructions)
+struct RowCol {
+    int i, c, qi, qc, width;
+    __device__ __forceinline__ RowCol(int lane, int width_) : width(width_)
+    {
+        i = lane / width; c = lane - i * width;
+        qi = 64 / width; qc = 64 - qi * width;
+    }
+    __device__ __forceinline__ void next()
+    {
+        i += qi; c += qc;
+        if (c >= width) { c -= width; ++i; }
+    }
+};
+
 __device__ __forceinline__ void zero_pad_columns(const GnnFusedArgs &a, float *X, int lane, int KP)
 {
     const int padw = KP - a.in_s;
-    for (int t = lane; t < 32 * padw; t += 64) {
-        const int i = t / padw, c = t - i * padw;
-        X[i * KP + a.in_s + c] = 0.0f;
-    }
+    RowCol rc(lane, padw);
+    for (int t = lane; t < 32 * padw; t += 64, rc.next()) X[rc.i * KP + a.in_s + rc.c] = 0.0f;
 }
 
 // Generic shapes (any Ds, partial tiles).  Correct for everything, tuned for nothing: small graphs are launch-bound.
@@ -505,26 +519,21 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
 {
     const int Ds = a.Ds, NLc = a.NLc;
     zero_pad_columns(a, X, lane, KP);
-    if (nvalid < 32)
-        for (int t = lane; t < (32 - nvalid) * a.in_s; t += 64) {
-            const int i = nvalid + t / a.in_s, c = t % a.in_s;
-            X[i * KP + c] = 0.0f;
-        }
+    if (nvalid < 32) {
+        RowCol rc(lane, a.in_s);
+        for (int t = lane; t < (32 - nvalid) * a.in_s; t += 64, rc.next()) X[(nvalid + rc.i) * KP + rc.c] = 0.0f;
+    }
     {   // own state rows (contiguous in HBM) into columns [0, Ds)
         const float *src = a.state_cur + (a.row_begin + i0) * Ds;
         const int total = nvalid * Ds;
-        for (int t = lane; t < total; t += 64) {
-            const int i = t / Ds, f = t - i * Ds;
-            X[i * KP + f] = gload1(src + t);
-        }
+        RowCol rc(lane, Ds);
+        for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + rc.c] = gload1(src + t);
     }
     if (a.IW > 0) {
         const float *src = a.inv + i0 * a.IW;
         const int total = nvalid * a.IW;
-        for (int t = lane; t < total; t += 64) {
-            const int i = t / a.IW, c = t - i * a.IW;
-            X[i * KP + label_col(c, Ds, NLc)] = gload1(src + t);
-        }
+        RowCol rc(lane, a.IW);
+        for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + label_col(rc.c, Ds, NLc)] = gload1(src + t);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (Ds <= 32) {
@@ -536,12 +545,29 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
         float acc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
-        for (int e = beg; e < end; ++e) {
-            const float w = gload1(a.adj_w + e);
-            const float *xp = a.state_cur + (int64_t)gload1(a.adj_src + e) * Ds + cbeg;
+        // four entries per round: their ids / weights are requested together, then their rows, then the fmaf chain in stored
+        // order - two memory latencies per round instead of two per entry
+        for (int e = beg; e < end; e += 4) {
+            float w[4];
+            const float *xp[4];
 #pragma unroll
-            for (int c = 0; c < 16; ++c)
-                if (cbeg + c < cend) acc[c] = __builtin_fmaf(w, gload1(xp + c), acc[c]);
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u < end ? e + u : e;        // clamp: a real entry, result unused
+                w[u] = gload1(a.adj_w + ee);
+                xp[u] = a.state_cur + (int64_t)gload1(a.adj_src + ee) * Ds + cbeg;
+            }
+            float x[4][16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[u][c] = (cbeg + c < cend) ? gload1(xp[u] + c) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < end) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (cbeg + c < cend) acc[c] = __builtin_fmaf(w[u], x[u][c], acc[c]);
+                }
         }
         if (node < nvalid) {
 #pragma unroll
@@ -726,10 +752,8 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
     if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
     float *dst = a.state_nxt + i0 * Ds;
     const int total = nvalid * Ds;
-    for (int t = lane; t < total; t += 64) {
-        const int i = t / Ds, f = t - i * Ds;
-        gptr_w(dst)[t] = X[i * KP + c_aggs + f];
-    }
+    RowCol rc(lane, Ds);
+    for (int t = lane; t < total; t += 64, rc.next()) gptr_w(dst)[t] = X[rc.i * KP + c_aggs + rc.c];
 }
 
 __device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int KP, int c_aggs)
