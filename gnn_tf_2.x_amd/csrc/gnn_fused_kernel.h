@@ -339,6 +339,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(v4i a, v4i b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// one (even, odd) element pair of split8: pieces of v0, v1 into dword j of the three operands
+__device__ __forceinline__ void split_pair(float v0, float v1, int &p0, int &p1, int &p2)
+{
+    const unsigned a = __float_as_uint(v0), b = __float_as_uint(v1);
+    const float ar = v0 - __uint_as_float(a & 0xffff0000u), br = v1 - __uint_as_float(b & 0xffff0000u);
+    const unsigned aru = __float_as_uint(ar), bru = __float_as_uint(br);
+    const float ar2 = ar - __uint_as_float(aru & 0xffff0000u), br2 = br - __uint_as_float(bru & 0xffff0000u);
+    p0 = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
+    p1 = (int)__builtin_amdgcn_perm(bru, aru, 0x07060302u);
+    p2 = (int)__builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302u);
+}
+
 // the six piece products of one K = 16 chunk on T output tiles; consecutive MFMAs go to different accumulators
 template <int T>
 __device__ __forceinline__ void mfma_split(const v4i (&w)[T][3], v4i b0, v4i b1, v4i b2, f32x16 *acc)
@@ -365,40 +377,43 @@ __device__ __forceinline__ void layer0_split(const float *xr, const int *wl, int
 {
     v4i wa[NO][3], wb[NO][3];
     float xa[8], xb[8];
+    v4i pa[3], pb[3];                                  // operand pieces of the chunk whose weights sit in wa / wb
 #define GNN_S0_LOAD(W, XV, C)                                                                       \
     _Pragma("unroll") for (int jt = 0; jt < NO; ++jt)                                               \
         _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                            \
             W[jt][pc] = gload4i(wl + (size_t)(((C) * NO + jt) * 3 + pc) * 256);                     \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) XV[i] = xr[16 * (C) + i];                         \
     __builtin_amdgcn_sched_barrier(0);
-#define GNN_S0_MFMA(W, XV)                                                                          \
+    // the six piece products of the chunk in W / P; after the first NO MFMAs the pieces of the NEXT chunk (values XN, already
+    // in registers) are cut in the shadow of the matrix pipe, one element pair per following MFMA
+#define GNN_S0_MFMA(W, P, XN, PN, Z)                                                                \
     {                                                                                               \
-        v4i b0, b1, b2;                                                                             \
-        split8(XV, b0, b1, b2);                                                                     \
-        mfma_split<NO>(W, b0, b1, b2, acc);                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                          \
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};                       \
+        _Pragma("unroll") for (int term = 0; term < 6; ++term)                                      \
+            _Pragma("unroll") for (int t = 0; t < NO; ++t) {                                        \
+                acc[t] = mfma_bf16(W[t][PA[term]], P[PB[term]], (Z && term == 0) ? f32x16{} : acc[t]);       \
+                const int m = term * NO + t;                                                        \
+                if (m >= NO && m < NO + 4) {                                                        \
+                    const int j = m - NO;                                                           \
+                    int q0, q1, q2;                                                                 \
+                    split_pair(XN[2 * j], XN[2 * j + 1], q0, q1, q2);                               \
+                    PN[0][j] = q0; PN[1][j] = q1; PN[2][j] = q2;                                    \
+                }                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                  \
+            }                                                                                       \
     }
     GNN_S0_LOAD(wa, xa, 0)
-    for (int c = 0; c < n_chunks; c += 2) {
-        GNN_S0_LOAD(wb, xb, c + 1)
-        GNN_S0_MFMA(wa, xa)
-        GNN_S0_LOAD(wa, xa, c + 2)
-        if (c + 1 < n_chunks) GNN_S0_MFMA(wb, xb)
+    split8(xa, pa[0], pa[1], pa[2]);
+    GNN_S0_LOAD(wb, xb, 1)
+    GNN_S0_MFMA(wa, pa, xb, pb, true)                  // chunk 0 starts the accumulators (C = 0: no zeroed register tiles)
+    for (int c = 1; c < n_chunks; c += 2) {
+        GNN_S0_LOAD(wa, xa, c + 1)
+        GNN_S0_MFMA(wb, pb, xa, pa, false)
+        GNN_S0_LOAD(wb, xb, c + 2)
+        if (c + 1 < n_chunks) GNN_S0_MFMA(wa, pa, xb, pb, false)
     }
 #undef GNN_S0_LOAD
 #undef GNN_S0_MFMA
-}
-
-// one (even, odd) element pair of split8: pieces of v0, v1 into dword j of the three operands
-__device__ __forceinline__ void split_pair(float v0, float v1, int &p0, int &p1, int &p2)
-{
-    const unsigned a = __float_as_uint(v0), b = __float_as_uint(v1);
-    const float ar = v0 - __uint_as_float(a & 0xffff0000u), br = v1 - __uint_as_float(b & 0xffff0000u);
-    const unsigned aru = __float_as_uint(ar), bru = __float_as_uint(br);
-    const float ar2 = ar - __uint_as_float(aru & 0xffff0000u), br2 = br - __uint_as_float(bru & 0xffff0000u);
-    p0 = (int)__builtin_amdgcn_perm(b, a, 0x07060302u);
-    p1 = (int)__builtin_amdgcn_perm(bru, aru, 0x07060302u);
-    p2 = (int)__builtin_amdgcn_perm(__float_as_uint(br2), __float_as_uint(ar2), 0x07060302u);
 }
 
 // hidden / last layer: input = accumulator tiles of the previous layer; its epilogue (bias + activation) is applied here,
@@ -458,7 +473,8 @@ __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const f
 #pragma unroll
                 for (int t = 0; t < TPU; ++t) {
                     const int *bq = bp[c & 1][PB[term]];
-                    acc[up * TPU + t] = mfma_bf16(w[u][t][PA[term]], v4i{bq[0], bq[1], bq[2], bq[3]}, acc[up * TPU + t]);
+                    // the first MFMA of an accumulator takes C = 0 (an inline constant) instead of a zeroed register tile
+                    acc[up * TPU + t] = mfma_bf16(w[u][t][PA[term]], v4i{bq[0], bq[1], bq[2], bq[3]}, (c == 0 && term == 0) ? f32x16{} : acc[up * TPU + t]);
                     // VALU tasks due after MFMA number m of the chunk: [(m - 1) NTASK / NM, m NTASK / NM)
                     const int m = (up * 6 + term) * TPU + t + 1;
                     const int k0 = (m - 1) * NTASK / NM, k1 = m * NTASK / NM;
@@ -864,22 +880,17 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
         asm volatile("" : "+s"(a.Ws[0]), "+s"(a.Ws[1]), "+s"(a.Ws[2]));
         const float *xr = X + (lane & 31) * KP + 8 * half;
         if constexpr (LAYERS == 1) {
-            zero_acc<NTL>(out);
             layer0_split<NTL>(xr, a.Ws[0] + 4 * lane, a.chunks0, out);
         } else {
             f32x16 h1[NT];
-            zero_acc<NT>(h1);
             layer0_split<NT>(xr, a.Ws[0] + 4 * lane, a.chunks0, h1);
             GNN_STAMP(3);
             GNN_STAMP(4);
             if constexpr (LAYERS == 2) {
-                zero_acc<NTL>(out);
                 layer_split_from_regs<NT, NTL, ACT>(h1, a.bias[0], half, out, a.Ws[1] + 4 * lane);
             } else {
                 f32x16 h2[NT];
-                zero_acc<NT>(h2);
                 layer_split_from_regs<NT, NT, ACT>(h1, a.bias[0], half, h2, a.Ws[1] + 4 * lane);
-                zero_acc<NTL>(out);
                 layer_split_from_regs<NT, NTL, ACT>(h2, a.bias[1], half, out, a.Ws[2] + 4 * lane);
             }
         }
