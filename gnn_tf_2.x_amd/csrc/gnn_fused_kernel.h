@@ -672,7 +672,8 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
     const int node_end = node + 8;
     const int e_begin = ipt[node], e_end = ipt[node_end];
     int next_end = ipt[node + 1];
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    // two packed accumulators: v_pk_fma_f32 does the two IEEE fmas of a pair in one issue slot (same bits as two v_fma_f32)
+    v2f acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     // neighbour rows through a buffer descriptor: 32-bit byte offsets (src * 256 + 16 * lane-in-row) instead of 64-bit
     // pointer arithmetic per row; the state replica is < 4 GiB by the fused path's precondition
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.state_cur), 0, (int)a.state_bytes, 0x00020000);
@@ -681,8 +682,8 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
 #define GNN_ROW_BOUNDARY(e)                                                                     \
     while ((e) >= next_end) {                                                                   \
         float *xr = xo + node * KP;                                                             \
-        xr[0] = acc0; xr[1] = acc1; xr[2] = acc2; xr[3] = acc3;                                 \
-        acc0 = acc1 = acc2 = acc3 = 0.0f;                                                       \
+        xr[0] = acc01.x; xr[1] = acc01.y; xr[2] = acc23.x; xr[3] = acc23.y;                     \
+        acc01 = v2f{0.f, 0.f}; acc23 = v2f{0.f, 0.f};                                           \
         ++node;                                                                                 \
         next_end = ipt[node + 1];                                                               \
     }
@@ -700,8 +701,8 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             GNN_ROW_BOUNDARY(base + u)
-            acc0 = __builtin_fmaf(w[u], x[u].x, acc0); acc1 = __builtin_fmaf(w[u], x[u].y, acc1);
-            acc2 = __builtin_fmaf(w[u], x[u].z, acc2); acc3 = __builtin_fmaf(w[u], x[u].w, acc3);
+            acc01 = __builtin_elementwise_fma(v2f{w[u], w[u]}, x[u].lo, acc01);
+            acc23 = __builtin_elementwise_fma(v2f{w[u], w[u]}, x[u].hi, acc23);
         }
     }
     {                                                                        // tail batch: cnt in [0, GB)
@@ -715,16 +716,16 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
         for (int u = 0; u < GB; ++u) {
             if (u < cnt) {
                 GNN_ROW_BOUNDARY(base + u)
-                acc0 = __builtin_fmaf(w[u], x[u].x, acc0); acc1 = __builtin_fmaf(w[u], x[u].y, acc1);
-                acc2 = __builtin_fmaf(w[u], x[u].z, acc2); acc3 = __builtin_fmaf(w[u], x[u].w, acc3);
+                acc01 = __builtin_elementwise_fma(v2f{w[u], w[u]}, x[u].lo, acc01);
+                acc23 = __builtin_elementwise_fma(v2f{w[u], w[u]}, x[u].hi, acc23);
             }
         }
     }
 #undef GNN_ROW_BOUNDARY
     for (; node < node_end; ++node) {                                        // last row with entries, then empty rows
         float *xr = xo + node * KP;
-        xr[0] = acc0; xr[1] = acc1; xr[2] = acc2; xr[3] = acc3;
-        acc0 = acc1 = acc2 = acc3 = 0.0f;
+        xr[0] = acc01.x; xr[1] = acc01.y; xr[2] = acc23.x; xr[3] = acc23.y;
+        acc01 = v2f{0.f, 0.f}; acc23 = v2f{0.f, 0.f};
     }
     // own state and label columns into the tile
 #pragma unroll
