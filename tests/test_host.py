@@ -154,6 +154,9 @@ def test_library_exports_every_declared_symbol():
     from GNN import _engine
     assert sorted(_engine.EXPORTS) == declared
     so = _engine.LIB_PATH
+    if not os.path.exists(so):          # fresh checkout: cross-compile for gfx950 (no GPU needed), exactly what build() does
+        import subprocess
+        subprocess.check_call(['make', '-C', os.path.join(ROOT, 'gnn_tf_2.x_amd', 'csrc'), '-j8'], stdout=subprocess.DEVNULL)
     assert os.path.exists(so), 'libgnn_hip.so not built: run __graft_entry__.build()'
     lib = ctypes.CDLL(so)
     for name in declared:
