@@ -195,9 +195,7 @@ class LGNN(BaseClass):
         i also receives the gradient that reaches it through the labels of layer i + 1 (update_graph, LGNN.py:227-260).
         ``state0`` / ``masks_*``: optional per-layer lists (tests inject them)."""
         from GNN import losses, _engine
-        if self.GNNS_TYPE == GNNedgeBased:
-            raise NotImplementedError("joint training ('parallel' / 'residual') of an edge-based LGNN is not implemented on the MI355X "
-                                      "engine yet (training_mode='serial' is)")
+        edge_based = self.GNNS_TYPE == GNNedgeBased
         if self.training_mode not in ('parallel', 'residual'):
             raise ValueError("training_step is the joint step of training_mode 'parallel' / 'residual'")
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
@@ -217,13 +215,17 @@ class LGNN(BaseClass):
         targets = self.GNNS_TYPE.get_filtered_tensor(g, g.targets)
         weights = self.GNNS_TYPE.get_filtered_tensor(g, g.sample_weights)
         base = g.device_graph(self.gnns[0].device)
+        if edge_based and not g.__dict__.get('_arc_order_set'):
+            base.set_arc_order(g.ArcNode[1], g.arcs[:, 2:])
+            g._arc_order_set = True
         derived = g.__dict__.setdefault('_lgnn_graphs', {})
         mask = g.loop_mask()
-        NLb = np.asarray(g.nodes).shape[1]
+        NLb, ALb = np.asarray(g.nodes).shape[1], np.asarray(g.arcs).shape[1] - 2
         # ---- forward ----
         current, loops, K, outs = base, [], [], []
         for idx, gnn in enumerate(self.gnns):
             loop = gnn._device_loop(current)
+            if edge_based: gnn._prepare_loop(g, loop, own_labels=current is not base)
             if gnn.state_vect_dim > 0:
                 gnn.seed += 1
                 loop.set_state0(state0[idx], gnn.seed)
@@ -236,10 +238,16 @@ class LGNN(BaseClass):
             loops.append(loop); K.append(k)
             outs.append(loop.readout(*g.nodegraph_csr()) if graph_based else out_nodes)
             if idx < L - 1:
-                extra = self.get_state * loop.Ds + self.get_output * loop.T
-                nxt = derived.get(extra)
-                if nxt is None:
-                    nxt = derived[extra] = base.derive(extra)
+                if edge_based:
+                    key = ('a', self.get_state * loop.Ds, self.get_output * loop.T)
+                    nxt = derived.get(key)
+                    if nxt is None:
+                        nxt = derived[key] = base.derive_edge(key[1], key[2])
+                else:
+                    key = self.get_state * loop.Ds + self.get_output * loop.T
+                    nxt = derived.get(key)
+                    if nxt is None:
+                        nxt = derived[key] = base.derive(key)
                 nxt.update_labels(base, loop, self.get_state, self.get_output)
                 current = nxt
         # ---- loss (reference LGNN.py:219-222) ----
@@ -257,15 +265,18 @@ class LGNN(BaseClass):
         for idx in reversed(range(L)):
             d_nodes_out = ng @ d_outs[idx] if graph_based else d_outs[idx]
             if d_out_extra is not None: d_nodes_out = d_nodes_out + d_out_extra
-            res = results[idx] = loops[idx].train_backward(d_nodes_out, d_state_extra, want_d_nodes=idx > 0 and (self.get_state or self.get_output))
+            chain = idx > 0
+            res = results[idx] = loops[idx].train_backward(d_nodes_out, d_state_extra,
+                                                           want_d_nodes=chain and (self.get_state or (self.get_output and not edge_based)),
+                                                           want_d_arcs=chain and edge_based and self.get_output)
             d_state_extra = d_out_extra = None
-            if idx > 0 and res['d_nodes'] is not None:
+            if chain:
                 prev, c = loops[idx - 1], NLb
                 if self.get_state:
                     d_state_extra = res['d_nodes'][:, c:c + prev.Ds]
                     c += prev.Ds
-                if self.get_output:
-                    d_out_extra = res['d_nodes'][mask, c:c + prev.T]
+                if self.get_output:     # the previous output sits on the arc labels of an edge-based layer, else on the node labels
+                    d_out_extra = res['d_arcs'][mask, ALb:ALb + prev.T] if edge_based else res['d_nodes'][mask, c:c + prev.T]
         # ---- update: net_state gradients / k when mean (GNN_BaseClass.py:241); one optimizer over all layers (:244-247) ----
         gs = [[a / k for a in r['grads_state']] if (mean and k) else r['grads_state'] for r, k in zip(results, K)]
         go = [r['grads_output'] for r in results]

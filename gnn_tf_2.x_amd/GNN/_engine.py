@@ -399,7 +399,7 @@ class Loop:
         self._train_nets = (net_state, net_output, int(k.value))
         return float(k.value), out
 
-    def train_backward(self, d_out_nodes, d_state_extra=None, want_d_nodes: bool = False):
+    def train_backward(self, d_out_nodes, d_state_extra=None, want_d_nodes: bool = False, want_d_arcs: bool = False):
         """gnn_loop_train_backward: dict(grads_state, grads_output (raw sums over the iterations), bn_batch_state,
         bn_batch_output, d_nodes [N, NL] or None)."""
         net_state, net_output, kk = self._train_nets
@@ -414,8 +414,10 @@ class Loop:
         if d_state_extra is not None:
             dse = _f32(d_state_extra)
             if dse.shape != (self.n_rows, self.Ds): raise ValueError(f'd_state_extra shape {dse.shape} != {(self.n_rows, self.Ds)}')
-        dn = np.zeros((self.n_rows, self.graph.dims()['NL']), np.float32) if want_d_nodes else None
-        _check(lib().gnn_loop_train_backward(self._h, _fp(d_out), _fp(dse), _fp(gs), _fp(go), _fp(bns), _fp(bno), _fp(dn)))
+        dims = self.graph.dims()
+        dn = np.zeros((self.n_rows, dims['NL']), np.float32) if want_d_nodes else None
+        da = np.zeros((dims['n_arcs'], dims['AL']), np.float32) if want_d_arcs else None
+        _check(lib().gnn_loop_train_backward(self._h, _fp(d_out), _fp(dse), _fp(gs), _fp(go), _fp(bns), _fp(bno), _fp(dn), _fp(da)))
 
         def split(flat, shp):
             out, off = [], 0
@@ -425,7 +427,7 @@ class Loop:
                 off += cnt
             return out
 
-        return dict(grads_state=split(gs, shp_s), grads_output=split(go, shp_o), bn_batch_state=bns[:kk], bn_batch_output=bno, d_nodes=dn)
+        return dict(grads_state=split(gs, shp_s), grads_output=split(go, shp_o), bn_batch_state=bns[:kk], bn_batch_output=bno, d_nodes=dn, d_arcs=da)
 
     def set_impl(self, impl: int) -> int:
         used = C.c_int(0)

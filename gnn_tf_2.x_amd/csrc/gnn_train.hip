@@ -480,6 +480,36 @@ __global__ void k_scatter_edge_grad(int64_t m, const int32_t *rows, const int32_
     else if (d_nodes) atomicAdd(d_nodes + node * NL + (c - Ds), v);
 }
 
+// acc[r, c] += d_inp[r, col0 + c]   (the loop-invariant aggregated arc labels receive gradient from every body)
+__global__ void k_add_cols(int64_t n, int width, const float *d_inp, int in_s, int col0, float *acc)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * width) return;
+    const int64_t r = t / width;
+    const int c = (int)(t - r * width);
+    acc[t] += d_inp[r * in_s + col0 + c];
+}
+
+// d arc labels, ORIGINAL arc order.  (a) label columns of the per-arc readout rows: row m <-> arc position rows[m];
+// (b) ArcNode^T . arc labels: entry q of destination dst carries arc arc_id[q] with weight arc_w[q].  Targets are unique.
+__global__ void k_arc_grad_readout(int64_t m, int AL, const int32_t *rows, const float *d_feats, int we, int col0, float *d_arcs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * AL) return;
+    const int64_t q = t / AL;
+    const int c = (int)(t - q * AL);
+    d_arcs[(int64_t)rows[q] * AL + c] += d_feats[q * we + col0 + c];
+}
+
+__global__ void k_arc_grad_agg(int64_t e, int AL, const int32_t *entry_dst, const int32_t *arc_id, const float *arc_w, const float *d_agg, float *d_arcs)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= e * AL) return;
+    const int64_t q = t / AL;
+    const int c = (int)(t - q * AL);
+    d_arcs[(int64_t)arc_id[q] * AL + c] += arc_w[q] * d_agg[(int64_t)entry_dst[q] * AL + c];
+}
+
 __global__ void k_axpy1(int64_t n, const float *x, float *y)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,7 +699,8 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
 }
 
 extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
-                                       float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host)
+                                       float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host,
+                                       float *d_arcs_host)
 {
     ARGCHK(l && grads_state && grads_output, "bad arguments");
     TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
@@ -691,6 +722,15 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
     if (d_state_extra) { if (N) HIPCHK(hipMemcpyAsync(d_state, d_state_extra, sizeof(float) * (size_t)N * Ds, hipMemcpyHostToDevice, st)); }
     else HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)N * Ds, st));
     const bool want_nodes = d_nodes_host != nullptr;
+    const bool want_arcs = d_arcs_host != nullptr && g->AL > 0;
+    const int AL = g->AL, c_agga = c_aggn + NLc;
+    float *d_arcs = nullptr, *d_aa = nullptr;
+    if (want_arcs) {
+        ARGCHK(l->edge_mode && g->sh->arc_id, "d_arc_labels: edge-based loop on a graph with gnn_graph_set_arc_order required");
+        if ((rc = buf.get(&d_arcs, (size_t)g->E * AL)) || (rc = buf.get(&d_aa, (size_t)N * AL))) return rc;
+        HIPCHK(hipMemsetAsync(d_arcs, 0, sizeof(float) * std::max<size_t>(1, (size_t)g->E * AL), st));
+        HIPCHK(hipMemsetAsync(d_aa, 0, sizeof(float) * std::max<size_t>(1, (size_t)N * AL), st));
+    }
     if (want_nodes && l->D) {
         if ((rc = buf.get(&d_nodes, (size_t)N * NL)) || (rc = buf.get(&via, (size_t)N * NL))) return rc;
         HIPCHK(hipMemsetAsync(d_nodes, 0, sizeof(float) * (size_t)N * NL, st));
@@ -728,6 +768,10 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
             hipLaunchKernelGGL(k_combine, cdiv(N * Ds, 256), 256, 0, st, N, Ds, d_inp, in_s, tmp, d_state);
             HIPCHK(hipGetLastError());
         }
+        if (want_arcs && N) {
+            hipLaunchKernelGGL(k_add_cols, cdiv(N * AL, 256), 256, 0, st, N, AL, d_inp, in_s, c_agga, d_aa);
+            HIPCHK(hipGetLastError());
+        }
         if (want_nodes && l->D && N) {    // labels enter each body directly and through aggregated_nodes (GNN.py:228, :263)
             if ((rc = gnn_launch_spmm(st, N, cx->d_sip, cx->d_sdst, cx->d_sw, d_inp + c_aggn, NL, in_s, via, NL, nullptr, 1))) return rc;
             hipLaunchKernelGGL(k_nodes_grad, cdiv(N * NL, 256), 256, 0, st, N, NL, d_inp, in_s, c_nodes, via, d_nodes);
@@ -740,6 +784,12 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
         for (int it = 0; it < k; ++it)
             HIPCHK(hipMemcpyAsync(bn_batch_state + (size_t)it * 2 * Ds, cx->caches[it].stats, sizeof(float) * 2 * Ds, hipMemcpyDeviceToHost, st));
     if (bn_batch_output && l->ou->has_bn && M) HIPCHK(hipMemcpyAsync(bn_batch_output, cx->co.stats, sizeof(float) * 2 * T, hipMemcpyDeviceToHost, st));
+    if (want_arcs && g->E) {
+        if (M) hipLaunchKernelGGL(k_arc_grad_readout, cdiv(M * AL, 256), 256, 0, st, M, AL, l->edge_rows, d_feats, wf, 2 * (Ds + NLc), d_arcs);
+        hipLaunchKernelGGL(k_arc_grad_agg, cdiv(g->E * AL, 256), 256, 0, st, g->E, AL, l->edge_dst, g->sh->arc_id, g->sh->arc_w, d_aa, d_arcs);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(d_arcs_host, d_arcs, sizeof(float) * (size_t)g->E * AL, hipMemcpyDeviceToHost, st));
+    }
     if (want_nodes && N)        // D == 0: state_0 = nodes (GNN.py:265), so the gradient of the initial state IS the label gradient
         HIPCHK(hipMemcpyAsync(d_nodes_host, l->D ? d_nodes : d_state, sizeof(float) * (size_t)N * NL, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -779,7 +829,7 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
     } else {
         loss_host(loss_kind, M, T, targets, h_out.data(), sample_weights, &loss, h_dnodes);
     }
-    rc = gnn_loop_train_backward(l, h_dnodes.data(), nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr);
+    rc = gnn_loop_train_backward(l, h_dnodes.data(), nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr, nullptr);
     if (rc) return rc;
     *loss_out = (float)loss;
     return GNN_OK;

@@ -163,15 +163,17 @@ int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *s
  *                    training-mode state / outputs become the loop's result (gnn_loop_get_state / get_output / readout,
  *                    gnn_graph_update_labels), and the context of the backward pass stays with the loop.
  *   gnn_loop_train_backward  d_out_nodes [n_masked, T] = d loss / d out_nodes; d_state_extra [N, Ds] (or NULL) = an extra
- *                    gradient on the final state; d_nodes [N, NL] (or NULL) receives d loss / d node labels.  One
- *                    backward per forward.
+ *                    gradient on the final state; d_nodes [N, NL] (or NULL) receives d loss / d node labels; d_arc_labels
+ *                    [n_arcs, AL] (or NULL; edge-based loops after gnn_graph_set_arc_order) d loss / d arc labels in
+ *                    ORIGINAL arc order (LGNN.py:253-254).  One backward per forward.
  *   gnn_loss_grad    host helper: *loss = sum_i w_i L(t_i, out_i) and d_out = d loss / d out (may be NULL). */
 int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
                            const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
                            const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
                            float *k_out, float *out_nodes);
 int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
-                            float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes);
+                            float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes,
+                            float *d_arc_labels);
 int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets, const float *out,
                   const float *sample_weights, double *loss, float *d_out);
 /* selects the implementation:

@@ -161,11 +161,14 @@ def train_forward(g, net_state, net_output, state_vect_dim, max_iteration, thres
                 state=state, out_nodes=out_nodes, moving_state=mov_s, moving_output=mov_o, dtype=dtype, edge_based=edge_based)
 
 
-def train_backward(ctx, d_out_nodes, d_state_extra=None):
+def train_backward(ctx, d_out_nodes, d_state_extra=None, want_d_arcs=False):
     """Back-propagation through net_output and the k executed bodies.  d_out_nodes: d loss / d out_nodes [M, T];
     d_state_extra: an additional gradient on the FINAL state [N, Ds] (LGNN: the next layer's labels contain it).
     Returns (grads_state summed over the iterations, grads_output, d_nodes [N, NL]): d_nodes is the gradient with
-    respect to the node labels this layer saw (LGNN: they contain the previous layer's state / output)."""
+    respect to the node labels this layer saw (LGNN: they contain the previous layer's state / output).
+    want_d_arcs: also return d loss / d arc labels [E, AL] in ORIGINAL arc order (edge-based LGNN: the arc labels contain the
+    previous layer's output, LGNN.py:253-254): the label columns of the per-arc readout rows, and ArcNode^T . arc labels
+    (GNN.py:259), a loop-invariant term that enters every body."""
     g, dtype, k = ctx['g'], ctx['dtype'], ctx['k']
     net_state, net_output, D = ctx['net_state'], ctx['net_output'], ctx['D']
     nodes = np.asarray(g['nodes'], dtype)
@@ -194,6 +197,13 @@ def train_backward(ctx, d_out_nodes, d_state_extra=None):
     grads_s = None
     c_aggs = ds + (nl if D else 0)
     c_aggn = c_aggs + ds
+    c_agga = c_aggn + (nl if D else 0)
+    al = np.asarray(g['arcs']).shape[1] - 2
+    d_arcs = np.zeros((np.asarray(g['arcs']).shape[0], al), dtype)
+    d_agg_arcs = np.zeros((n, al), dtype)
+    if want_d_arcs and ctx.get('edge_based'):
+        wn_ = ds + (nl if D else 0)
+        d_arcs[np.nonzero(mask)[0]] += d_feats[:, 2 * wn_:2 * wn_ + al]     # readout row m <-> arc position p (paired by position)
     for it in reversed(range(k)):
         d_inp, gk = mlp_train_backward(d_state, net_state, ctx['caches'][it], dtype)
         grads_s = gk if grads_s is None else [a + b for a, b in zip(grads_s, gk)]
@@ -203,11 +213,18 @@ def train_backward(ctx, d_out_nodes, d_state_extra=None):
         if D:       # node labels enter every iteration directly and through aggregated_nodes (GNN.py:228, :263)
             d_nodes += d_inp[:, ds:ds + nl]
             np.add.at(d_nodes, src, w[:, None] * d_inp[dst, c_aggn:c_aggn + nl])
+        d_agg_arcs += d_inp[:, c_agga:c_agga + al]
     if not D:
         d_nodes = d_state           # state_0 = nodes (GNN.py:265)
+    if want_d_arcs:
+        ip_a, arc_id, w_a = g['arcT']
+        dst_a = np.repeat(np.arange(n), np.diff(ip_a))
+        d_arcs[arc_id] += np.asarray(w_a, dtype)[:, None] * d_agg_arcs[dst_a]
     if grads_s is None:
         n_st = len(net_state['activations'])
         grads_s = [np.zeros_like(np.asarray(v, dtype)) for v in net_state['weights'][:2 * n_st + (2 if net_state['batch_normalization'] else 0)]]
+    if want_d_arcs:
+        return grads_s, grads_o, d_nodes, d_arcs
     return grads_s, grads_o, d_nodes
 
 
@@ -236,7 +253,7 @@ def train_step(g, net_state, net_output, state_vect_dim, max_iteration, threshol
 
 
 def lgnn_train_step(g, layers, get_state, get_output, training_mode, state0, masks_state, masks_output, targets, sample_weights,
-                    loss='categorical_crossentropy', mean=True, graph_based=False, dtype=np.float64):
+                    loss='categorical_crossentropy', mean=True, graph_based=False, dtype=np.float64, edge_based=False):
     """Joint training step of an LGNN in 'parallel' or 'residual' mode (LGNN.py:201-224 inside GNN_BaseClass.py:231-247):
     the tape spans the whole stack, so layer i also receives gradient through the labels of layer i + 1
     (update_graph, LGNN.py:227-260: [nodes | state_i? | scatter(out_i)?]).
@@ -246,23 +263,25 @@ def lgnn_train_step(g, layers, get_state, get_output, training_mode, state0, mas
     assert training_mode in ('parallel', 'residual')
     L = len(layers)
     nodes0 = np.asarray(g['nodes'], dtype)
-    nlb = nodes0.shape[1]
+    arcs0 = np.asarray(g['arcs'], dtype)
+    nlb, alb = nodes0.shape[1], arcs0.shape[1] - 2
     ctxs, outs = [], []
     cur = g
     ng = np.asarray(g['NodeGraph'], dtype) if graph_based else None
     for i, ly in enumerate(layers):
         ctx = train_forward(cur, ly['net_state'], ly['net_output'], ly['state_vect_dim'], ly['max_iteration'], ly['threshold'],
-                            state0[i], masks_state[i], masks_output[i], dtype=dtype)
+                            state0[i], masks_state[i], masks_output[i], dtype=dtype, edge_based=edge_based)
         ctxs.append(ctx)
         outs.append(ng.T @ ctx['out_nodes'] if graph_based else ctx['out_nodes'])
         if i < L - 1:
             extra = []
+            cur = dict(g)
             if get_state: extra.append(ctx['state'])
             if get_output:
-                sc = np.zeros((nodes0.shape[0], ctx['out_nodes'].shape[1]), dtype)
+                sc = np.zeros((len(ctx['mask']), ctx['out_nodes'].shape[1]), dtype)
                 sc[ctx['mask']] = ctx['out_nodes']
-                extra.append(sc)
-            cur = dict(g)
+                if edge_based: cur['arcs'] = np.concatenate([arcs0, sc], axis=1)      # LGNN.py:253-254
+                else: extra.append(sc)
             cur['nodes'] = np.concatenate([nodes0] + extra, axis=1)
     if training_mode == 'residual':
         loss_value, d = loss_forward_backward(loss, targets, np.mean(outs, axis=0), sample_weights, dtype)
@@ -278,7 +297,10 @@ def lgnn_train_step(g, layers, get_state, get_output, training_mode, state0, mas
         d_nodes_out = ng @ d_outs[i] if graph_based else d_outs[i]
         if d_out_extra is not None:
             d_nodes_out = d_nodes_out + d_out_extra
-        gs, go, d_nodes = train_backward(ctx, d_nodes_out, d_state_extra)
+        if edge_based:
+            gs, go, d_nodes, d_arcs = train_backward(ctx, d_nodes_out, d_state_extra, want_d_arcs=True)
+        else:
+            gs, go, d_nodes = train_backward(ctx, d_nodes_out, d_state_extra)
         if mean and ctx['k']:
             gs = [v / ctx['k'] for v in gs]
         grads_s[i], grads_o[i] = gs, go
@@ -290,7 +312,8 @@ def lgnn_train_step(g, layers, get_state, get_output, training_mode, state0, mas
                 d_state_extra = d_nodes[:, c:c + prev['state'].shape[1]]
                 c += prev['state'].shape[1]
             if get_output:
-                d_out_extra = d_nodes[prev['mask'], c:c + prev['out_nodes'].shape[1]]
+                if edge_based: d_out_extra = d_arcs[prev['mask'], alb:alb + prev['out_nodes'].shape[1]]
+                else: d_out_extra = d_nodes[prev['mask'], c:c + prev['out_nodes'].shape[1]]
     return dict(k=[float(c['k']) for c in ctxs], loss=loss_value, grads_state=grads_s, grads_output=grads_o, outs=outs)
 
 

@@ -309,3 +309,65 @@ def test_edge_based_training_step_matches_oracle(d):
     before = gnn2.test(go2)['Loss']
     gnn2.train(go2, 25, None, update_freq=25, verbose=0)
     assert gnn2.test(go2)['Loss'] < 0.7 * before
+
+
+@pytest.mark.parametrize('d,get_state,get_output,mode', [(4, True, True, 'parallel'), (0, False, True, 'residual')])
+def test_edge_lgnn_joint_training_step_matches_oracle(d, get_state, get_output, mode):
+    """Edge-based LGNN in 'parallel' / 'residual' mode: the arc-label gradient (gnn_loop_train_backward: d_arc_labels) carries
+    layer i + 1's loss back to layer i's outputs (reference LGNN.py:253-254 under GNN_BaseClass.py:231-247)."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNedgeBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import Sequential, Dense, Dropout, BatchNormalization
+    from GNN.graph_class import GraphObject, GraphTensor
+    rng = np.random.default_rng(90 + d)
+    n, nl, al, t, max_it, L = 150, 3, 2, 2, 3, 3
+    arcs = random_arcs(rng, n, 400, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    e = len(arcs)
+    set_mask = rng.random(e) < 0.75
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    g['set_mask'], g['output_mask'] = set_mask, np.ones(e, bool)
+    m = int(set_mask.sum())
+    targets_full = rng.random((e, t)).astype(np.float32)
+    weights_full = rng.uniform(0.5, 1.5, e).astype(np.float32)
+
+    def sequential(net):
+        layers = []
+        for l in range(len(net['activations'])):
+            if net['dropout'].get(l): layers.append(Dropout(net['dropout'][l]))
+            layers.append(Dense(net['weights'][2 * l].shape[1], net['activations'][l], input_shape=(net['weights'][2 * l].shape[0],)))
+        if net['batch_normalization']: layers.append(BatchNormalization())
+        seq = Sequential(layers)
+        seq.set_weights([np.asarray(w, np.float32) for w in net['weights']])
+        return seq
+
+    layers, s0, ms, mo, gnns = [], [], [], [], []
+    for i in range(L):
+        ins, ls = orc.get_inout_dims('state', nl, al, t, 'a', d, [10], layer=i, get_state=get_state, get_output=get_output)
+        ino, lo = orc.get_inout_dims('output', nl, al, t, 'a', d, None, layer=i, get_state=get_state, get_output=get_output)
+        st = make_mlp(rng, ins, ls, 'tanh', gain=0.8, bn_random=True)
+        ou = make_mlp(rng, ino, lo, 'tanh', out_activation='softmax', bn_random=True)
+        st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1}
+        layers.append(dict(net_state=st, net_output=ou, state_vect_dim=d, max_iteration=max_it, threshold=0.0))
+        s0.append((0.1 * rng.standard_normal((n, d))).astype(np.float32) if d else None)
+        ms.append([{0: rng.random((n, ins)) > 0.2} for _ in range(max_it)])
+        mo.append({0: rng.random((m, ino)) > 0.1})
+        gnns.append(GNNedgeBased(net_state=sequential(st), net_output=sequential(ou), optimizer=None, loss_function=None, loss_arguments=None,
+                                 state_vect_dim=d, max_iteration=max_it, threshold=0.0, addressed_problem='r'))
+    ref = tro.lgnn_train_step(g, layers, get_state, get_output, mode, s0, ms, mo, targets_full[set_mask], weights_full[set_mask],
+                              loss='mean_squared_error', mean=False, edge_based=True)
+    lgnn = LGNN(gnns, get_state, get_output, optimizers.SGD(0.0), losses.mean_squared_error, None, 'r')
+    lgnn.training_mode = mode
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=targets_full, set_mask=set_mask, sample_weights=weights_full, problem_based='a',
+                     aggregation_mode='average')
+    res = lgnn.training_step(GraphTensor.fromGraphObject(go), mean=False, state0=s0,
+                             masks_state=[np.concatenate([mk[0].astype(np.uint8).ravel() for mk in msl]) for msl in ms],
+                             masks_output=[mol[0].astype(np.uint8).ravel() for mol in mo])
+    assert res['k'] == ref['k']
+    assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    for li in range(L):
+        np.testing.assert_allclose(res['outs'][li], ref['outs'][li], atol=2e-5)
+        for got, want in list(zip(res['grads_state'][li], ref['grads_state'][li])) + list(zip(res['grads_output'][li], ref['grads_output'][li])):
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want))), (li, got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)))

@@ -190,3 +190,46 @@ def test_edge_based_gradients_match_finite_differences(d):
                 w[idx] = old
                 fd = (lp - lm) / (2 * eps)
                 assert abs(fd - grads[wi][idx]) <= 1e-5 * max(1.0, abs(fd)), (wi, idx, fd, grads[wi][idx])
+
+
+@pytest.mark.parametrize('d,get_state,get_output,mode', [(3, True, True, 'parallel'), (0, False, True, 'residual'), (2, True, False, 'parallel')])
+def test_edge_lgnn_joint_gradients_match_finite_differences(d, get_state, get_output, mode):
+    """Edge-based LGNN, joint training: layer i also receives gradient through the ARC labels of layer i + 1 (LGNN.py:253-254)."""
+    rng = np.random.default_rng(31 + d)
+    n, nl, al, t, L = 24, 3, 2, 2, 3
+    arcs = random_arcs(rng, n, 60, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    e = len(g['arcs'])
+    g['set_mask'], g['output_mask'] = rng.random(e) < 0.75, np.ones(e, bool)
+    m = int(g['set_mask'].sum())
+    layers, s0, ms, mo = [], [], [], []
+    for i in range(L):
+        ins, ls = orc.get_inout_dims('state', nl, al, t, 'a', d, [6], layer=i, get_state=get_state, get_output=get_output)
+        ino, lo = orc.get_inout_dims('output', nl, al, t, 'a', d, None, layer=i, get_state=get_state, get_output=get_output)
+        st = make_mlp(rng, ins, ls, 'tanh', gain=0.8, bn_random=True)
+        ou = make_mlp(rng, ino, lo, 'tanh', out_activation='softmax', bn_random=True)
+        st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1}
+        layers.append(dict(net_state=st, net_output=ou, state_vect_dim=d, max_iteration=3, threshold=0.0))
+        s0.append(0.1 * rng.standard_normal((n, d)) if d else None)
+        ms.append([{0: rng.random((n, ins)) > 0.2} for _ in range(3)])
+        mo.append({0: rng.random((m, ino)) > 0.1})
+    targets = rng.random((m, t))
+    weights = rng.uniform(0.5, 1.5, m)
+    kw = dict(get_state=get_state, get_output=get_output, training_mode=mode, state0=s0, masks_state=ms, masks_output=mo, targets=targets,
+              sample_weights=weights, loss='mean_squared_error', mean=False, edge_based=True)
+    res = tro.lgnn_train_step(g, layers, **kw)
+    assert res['k'] == [3.0] * L and np.isfinite(res['loss'])
+    eps = 1e-6
+    for li, ly in enumerate(layers):
+        for net, grads in ((ly['net_state'], res['grads_state'][li]), (ly['net_output'], res['grads_output'][li])):
+            for wi in range(len(grads)):
+                w = net['weights'][wi] = np.asarray(net['weights'][wi], np.float64)
+                for _ in range(2):
+                    idx = tuple(rng.integers(0, s_) for s_ in w.shape)
+                    old = w[idx]
+                    w[idx] = old + eps; lp = tro.lgnn_train_step(g, layers, **kw)['loss']
+                    w[idx] = old - eps; lm = tro.lgnn_train_step(g, layers, **kw)['loss']
+                    w[idx] = old
+                    fd = (lp - lm) / (2 * eps)
+                    assert abs(fd - grads[wi][idx]) <= 2e-5 * max(1.0, abs(fd)), (li, wi, idx, fd, grads[wi][idx])
