@@ -104,13 +104,26 @@ class GNNnodeBased(BaseClass):
         return loop
 
     def _run(self, dev_graph: _engine.Graph, training: bool, state0) -> tuple[float, _engine.Loop]:
-        if training:
-            raise NotImplementedError('Loop(training=True): Dropout masks / BatchNormalization batch statistics and the tape for '
-                                      'back-propagation are not implemented on the MI355X engine yet')
         loop = self._device_loop(dev_graph)
         if self.state_vect_dim > 0:
             loop.set_state0(state0, self.seed)
+        if training:
+            return self._train_forward(loop), loop
         return loop.run(False), loop
+
+    def _train_forward(self, loop) -> float:
+        """Loop(training=True) (reference GNN.py:251-280 with the Keras layers in training mode): Dropout with fresh masks,
+        BatchNormalization on batch statistics (the moving statistics are updated as Keras does on every training-mode call).
+        The loop then holds the training-mode state / outputs."""
+        self._train_calls = getattr(self, '_train_calls', 0) + 1
+        k, _ = loop.train_forward(self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device), None,
+                                  dropout_state=self.net_state.dropout_rates(), dropout_output=self.net_output.dropout_rates(),
+                                  seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),
+                                  bn_output=self.net_output.bn_gamma_beta())
+        res = loop.train_backward(np.zeros((loop.n_masked, loop.T), np.float32))      # releases the context; yields the batch statistics
+        self.net_state.update_moving_statistics(res['bn_batch_state'])
+        if loop.n_masked: self.net_output.update_moving_statistics(res['bn_batch_output'])
+        return k
 
     # ---- training -------------------------------------------------------------------------------------------------------
     _graph_based = False
@@ -169,14 +182,12 @@ class GNNedgeBased(GNNnodeBased):
 
     def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
-        if training:
-            raise NotImplementedError('Loop(training=True) is not implemented on the MI355X engine yet')
         dev = g.device_graph(self.device)
         loop = self._device_loop(dev)
         self._prepare_loop(g, loop)
         if self.state_vect_dim > 0:
             loop.set_state0(state0, self.seed)
-        k = loop.run(False)
+        k = self._train_forward(loop) if training else loop.run(False)
         return k, loop.state(), loop.output()
 
     def _prepare_loop(self, g: GraphTensor, loop, own_labels: bool = False) -> None:

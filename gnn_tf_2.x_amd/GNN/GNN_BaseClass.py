@@ -4,9 +4,9 @@
 Everything here is host-side orchestration around ``Loop`` (which runs on the MI355X).  Differences from the reference,
 all deliberate:
   * the constructor does NOT delete ``path_writer`` (reference GNN_BaseClass.py:58 rmtree's it); call ``clear_writer()``;
-  * ``train`` computes its gradients on the device (``gnn_loop_train_step``: training-mode forward, loss, back-propagation
-    through the unrolled loop) and applies the optimizer on the host; TensorBoard summaries are not written.  Model types
-    without a device backward pass (edge-based GNN, LGNN) raise ``NotImplementedError`` rather than fall back to a CPU.
+  * ``train`` computes its gradients on the device (``gnn_loop_train_step`` / ``gnn_loop_train_forward`` + ``_backward``:
+    training-mode forward, loss, back-propagation through the unrolled loop) and applies the optimizer on the host;
+    TensorBoard summaries are not written.  Nothing falls back to a CPU.
 """
 from __future__ import annotations
 

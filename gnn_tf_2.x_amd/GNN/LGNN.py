@@ -126,8 +126,6 @@ class LGNN(BaseClass):
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
         graph_based = self.GNNS_TYPE == GNNgraphBased
         edge_based = self.GNNS_TYPE == GNNedgeBased
-        if edge_based and training:
-            raise NotImplementedError('Loop(training=True) of an edge-based LGNN is not implemented on the MI355X engine yet')
         if graph_based:
             if g.NodeGraph is None: raise ValueError('WRONG GNN. NodeGraph is None: GNN is graph-based, while problem is non graph-based.')
             if not g.loop_mask().all(): raise ValueError('graph-based GNN needs set_mask and output_mask all True')
@@ -145,7 +143,7 @@ class LGNN(BaseClass):
                 loop = gnn._device_loop(current)
                 gnn._prepare_loop(g, loop, own_labels=current is not base)
                 if gnn.state_vect_dim > 0: loop.set_state0(state0[idx], gnn.seed)
-                k = loop.run(False)
+                k = gnn._train_forward(loop) if training else loop.run(False)
             else:
                 k, loop = gnn._run(current, training, state0[idx])
             K.append(k)

@@ -371,3 +371,63 @@ def test_edge_lgnn_joint_training_step_matches_oracle(d, get_state, get_output, 
         for got, want in list(zip(res['grads_state'][li], ref['grads_state'][li])) + list(zip(res['grads_output'][li], ref['grads_output'][li])):
             assert got.shape == want.shape
             assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want))), (li, got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)))
+
+
+@pytest.mark.parametrize('cls_name', ['GNNnodeBased', 'GNNgraphBased', 'GNNedgeBased'])
+def test_loop_training_mode_forward(cls_name):
+    """Loop(g, training=True) (reference GNN.py:251-280 with Keras layers in training mode): BatchNormalization on batch
+    statistics (no Dropout here, so the oracle needs no masks); moving statistics move once per BN call."""
+    import GNN.GNN as G
+    from GNN import losses
+    from GNN.MLP import MLP
+    from GNN.graph_class import GraphObject, GraphTensor
+    cls = getattr(G, cls_name)
+    rng = np.random.default_rng(7)
+    n, nl, al, d, t = 120, 3, 2, 5, 2
+    arcs = random_arcs(rng, n, 300, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    e = len(arcs)
+    pb = {'GNNnodeBased': 'n', 'GNNgraphBased': 'g', 'GNNedgeBased': 'a'}[cls_name]
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    kw = {}
+    if pb == 'a':
+        g['set_mask'], g['output_mask'] = rng.random(e) < 0.8, np.ones(e, bool)
+        kw = dict(set_mask=g['set_mask'])
+        n_t = e
+    elif pb == 'g':
+        ng = np.zeros((n, 2), np.float32); ng[:70, 0] = 1 / 70; ng[70:, 1] = 1 / 50
+        g['NodeGraph'] = ng
+        kw = dict(NodeGraph=ng)
+        n_t = 2
+    else:
+        g['set_mask'] = rng.random(n) < 0.8
+        kw = dict(set_mask=g['set_mask'])
+        n_t = n
+    ins, ls = orc.get_inout_dims('state', nl, al, t, pb, d, [9])
+    ino, lo = orc.get_inout_dims('output', nl, al, t, pb, d, None)
+    st, ou = make_mlp(rng, ins, ls, 'tanh', gain=0.7, bn_random=True), make_mlp(rng, ino, lo, 'tanh', out_activation='softmax', bn_random=True)
+    st['dropout'], ou['dropout'] = {}, {}
+
+    def build(net):
+        m = MLP(input_dim=net['weights'][0].shape[0], layers=[w.shape[1] for w in net['weights'][0:2 * len(net['activations']):2]],
+                activations=net['activations'], kernel_initializer='zeros', bias_initializer='zeros')
+        m.set_weights([np.asarray(w, np.float32) for w in net['weights']])
+        return m
+
+    gnn = cls(net_state=build(st), net_output=build(ou), optimizer=None, loss_function=losses.mean_squared_error, loss_arguments=None,
+              state_vect_dim=d, max_iteration=4, threshold=0.0, addressed_problem='r')
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=rng.random((n_t, t)), problem_based=pb, aggregation_mode='average', **kw)
+    gt = GraphTensor.fromGraphObject(go)
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    k, state, out = gnn.Loop(gt, training=True, state0=s0)
+    ctx = tro.train_forward(g, st, ou, d, 4, 0.0, s0, [{}] * 4, {}, edge_based=pb == 'a')
+    want = ctx['out_nodes'] if pb != 'g' else np.asarray(g['NodeGraph'], np.float64).T @ ctx['out_nodes']
+    assert k == ctx['k'] == 4
+    assert np.max(np.abs(state - ctx['state'])) < 2e-5 and np.max(np.abs(out - want)) < 2e-5
+    mm, mv = gnn.net_state.layers[-1].moving_mean, gnn.net_state.layers[-1].moving_variance
+    np.testing.assert_allclose(mm, ctx['moving_state'][0], atol=1e-5)
+    np.testing.assert_allclose(mv, ctx['moving_state'][1], atol=1e-5)
+    it, loss, targs, o2 = gnn.evaluate_single_graph(gt, training=True)          # reference GNN.py:180-199
+    assert np.isfinite(loss) and targs.shape == o2.shape
+    k_inf, _, out_inf = gnn.Loop(gt, training=False, state0=s0)                  # inference mode still uses the moving statistics
+    assert out_inf.shape == out.shape and not np.allclose(out_inf, out, atol=1e-4)
