@@ -134,9 +134,6 @@ class GNNnodeBased(BaseClass):
         result of the device step (loss, k, gradients) for inspection."""
         from GNN import losses
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
-        for layer in self.get_dense_layers():
-            if layer.kernel_regularizer is not None or layer.bias_regularizer is not None:
-                raise NotImplementedError('kernel/bias regularizers are not implemented for training on the MI355X engine')
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
             raise TypeError('train() needs an optimizer with apply_gradients, e.g. GNN.optimizers.Adam()')
         kind = losses.device_loss_kind(self.loss_function, self.loss_args)
@@ -156,6 +153,14 @@ class GNNnodeBased(BaseClass):
                               seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),
                               bn_output=self.net_output.bn_gamma_beta(), max_iter=self.max_iteration)
         k = res['k']
+        # regularizer terms are part of the taped loss (reference GNN_BaseClass.py:223-235): their gradients join the device ones
+        from GNN import regularizers
+        for net, key in ((self.net_state, 'grads_state'), (self.net_output, 'grads_output')):
+            pen, rg = regularizers.penalty_and_gradients(net.dense_layers)
+            res['loss'] += pen
+            for li, (gk, gb) in enumerate(rg):
+                if gk is not None: res[key][2 * li] = res[key][2 * li] + gk
+                if gb is not None: res[key][2 * li + 1] = res[key][2 * li + 1] + gb
         gs = [a / k for a in res['grads_state']] if (mean and k) else res['grads_state']
         ws, wo = self.net_state.trainable_variables, self.net_output.trainable_variables
         new = self.optimizer.apply_gradients(zip(gs + res['grads_output'], ws + wo))

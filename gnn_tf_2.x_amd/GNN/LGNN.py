@@ -197,9 +197,6 @@ class LGNN(BaseClass):
         if self.training_mode not in ('parallel', 'residual'):
             raise ValueError("training_step is the joint step of training_mode 'parallel' / 'residual'")
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
-        for layer in self.get_dense_layers():
-            if layer.kernel_regularizer is not None or layer.bias_regularizer is not None:
-                raise NotImplementedError('kernel/bias regularizers are not implemented for training on the MI355X engine')
         if self.optimizer is None or not hasattr(self.optimizer, 'apply_gradients'):
             raise TypeError('train() needs an optimizer with apply_gradients, e.g. GNN.optimizers.Adam()')
         kind = losses.device_loss_kind(self.loss_function, self.loss_args)
@@ -276,6 +273,14 @@ class LGNN(BaseClass):
                 if self.get_output:     # the previous output sits on the arc labels of an edge-based layer, else on the node labels
                     d_out_extra = res['d_arcs'][mask, ALb:ALb + prev.T] if edge_based else res['d_nodes'][mask, c:c + prev.T]
         # ---- update: net_state gradients / k when mean (GNN_BaseClass.py:241); one optimizer over all layers (:244-247) ----
+        from GNN import regularizers
+        for gnn, r in zip(self.gnns, results):     # regularizer terms of the taped loss (reference GNN_BaseClass.py:223-235)
+            for net, key in ((gnn.net_state, 'grads_state'), (gnn.net_output, 'grads_output')):
+                pen, rg = regularizers.penalty_and_gradients(net.dense_layers)
+                loss += pen
+                for li, (gk, gb) in enumerate(rg):
+                    if gk is not None: r[key][2 * li] = r[key][2 * li] + gk
+                    if gb is not None: r[key][2 * li + 1] = r[key][2 * li + 1] + gb
         gs = [[a / k for a in r['grads_state']] if (mean and k) else r['grads_state'] for r, k in zip(results, K)]
         go = [r['grads_output'] for r in results]
         ws, wo = self.trainable_variables()

@@ -431,3 +431,30 @@ def test_loop_training_mode_forward(cls_name):
     assert np.isfinite(loss) and targs.shape == o2.shape
     k_inf, _, out_inf = gnn.Loop(gt, training=False, state0=s0)                  # inference mode still uses the moving statistics
     assert out_inf.shape == out.shape and not np.allclose(out_inf, out, atol=1e-4)
+
+
+def test_regularizers_join_the_device_gradients():
+    from GNN import losses, optimizers, regularizers
+    from GNN.GNN import GNNnodeBased
+    from GNN.MLP import MLP, set_seed
+    from GNN.graph_class import GraphObject, GraphTensor
+    rng = np.random.default_rng(3)
+    set_seed(3)
+    n = 80
+    go = GraphObject(arcs=random_arcs(rng, n, 200, 1), nodes=(2 * rng.random((n, 3)) - 1).astype(np.float32), targets=np.eye(2)[rng.integers(0, 2, n)])
+    gt = GraphTensor.fromGraphObject(go)
+
+    def model(reg):
+        set_seed(3)
+        st = MLP(1 + 2 * 3, [6, 3], 'tanh', 'glorot_normal', 'zeros', kernel_regularizer=reg, batch_normalization=False)
+        ou = MLP(3, [2], 'softmax', 'glorot_normal', 'zeros', bias_regularizer=reg, batch_normalization=False)
+        return GNNnodeBased(net_state=st, net_output=ou, optimizer=optimizers.SGD(0.0), loss_function=losses.categorical_crossentropy,
+                            loss_arguments=None, state_vect_dim=0, max_iteration=3, threshold=0.0, addressed_problem='c')
+
+    plain, reg = model(None), model(regularizers.l2(0.05))
+    a, b = plain.training_step(gt, mean=False), reg.training_step(gt, mean=False)
+    w = plain.net_state.get_weights()
+    assert b['loss'] > a['loss']
+    np.testing.assert_allclose(b['grads_state'][0], a['grads_state'][0] + 0.1 * w[0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b['grads_state'][1], a['grads_state'][1], rtol=1e-5, atol=1e-6)          # bias of net_state: no regularizer
+    np.testing.assert_allclose(b['grads_output'][1], a['grads_output'][1] + 0.1 * plain.net_output.get_weights()[1], rtol=1e-5, atol=1e-6)

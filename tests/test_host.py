@@ -189,3 +189,22 @@ def test_mutag_loader_follows_reference_semantics():
         arcs = np.concatenate([ids, eL[mask]], axis=1)
         assert np.array_equal(graphs[g].arcs, arcs.astype(np.float32))
         assert graphs[g].nodes.shape == (j - i, 14) and graphs[g].NodeGraph.shape == (j - i, 1)
+
+
+def test_regularizers_penalty_and_gradient():
+    """GNN.regularizers (the tf.keras.regularizers call convention, summed into the loss as reference GNN_BaseClass.py:223-228)."""
+    from GNN import regularizers
+    from GNN.MLP import MLP
+    rng = np.random.default_rng(0)
+    net = MLP(5, [4, 3], 'tanh', 'glorot_normal', 'zeros', kernel_regularizer=regularizers.l2(0.1), bias_regularizer=[None, regularizers.l1_l2(0.2, 0.3)],
+              batch_normalization=False)
+    net.set_weights([rng.standard_normal(w.shape).astype(np.float32) for w in net.get_weights()])
+    pen, grads = regularizers.penalty_and_gradients(net.dense_layers)
+    w = net.get_weights()
+    want = 0.1 * np.sum(w[0].astype(np.float64) ** 2) + 0.1 * np.sum(w[2].astype(np.float64) ** 2) + 0.2 * np.sum(np.abs(w[3])) + 0.3 * np.sum(w[3].astype(np.float64) ** 2)
+    assert abs(pen - want) < 1e-6 * max(1.0, abs(want))
+    assert grads[0][1] is None and np.allclose(grads[0][0], 0.2 * w[0]) and np.allclose(grads[1][0], 0.2 * w[2])
+    assert np.allclose(grads[1][1], 0.2 * np.sign(w[3]) + 0.6 * w[3])
+    with pytest.raises(TypeError):
+        bad = MLP(5, [2], 'tanh', 'zeros', 'zeros', kernel_regularizer=lambda x: 0.0, batch_normalization=False)
+        regularizers.penalty_and_gradients(bad.dense_layers)
