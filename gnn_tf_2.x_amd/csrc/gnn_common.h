@@ -115,6 +115,7 @@ struct gnn_graph {
     // derived graphs of an edge-based LGNN own widened arc labels: ArcNode^T order (aggregation) and original order (readout)
     float *arc_labels_own = nullptr, *arc_labels_orig_own = nullptr;
     int base_AL = 0;
+    uint64_t label_version = 1;   // bumped whenever node / arc labels are rewritten (gnn_graph_update_labels)
 };
 
 inline const float *gnn_graph_arc_labels(const gnn_graph *g) { return g->arc_labels_own ? g->arc_labels_own : g->sh->arc_labels; }
@@ -155,6 +156,7 @@ struct gnn_loop {
     float *state_init = nullptr;            // [n_rows, Ds] initial state of the owned rows (D > 0)
     float *inp = nullptr;                   // unfused: materialised concat [n_rows, in_s]
     float *inv = nullptr;                   // fused: loop-invariant label block [n_rows, inv_w]
+    uint64_t inv_version = 0;               // label_version of the graph the block was built from
     float *tmp[2] = {nullptr, nullptr};     // unfused: layer activations
     float *feats = nullptr, *out = nullptr, *otmp[2] = {nullptr, nullptr};
     int *flags = nullptr;                   // [(max_iter+2), world, GNN_FLAG_WORDS]

@@ -1342,6 +1342,7 @@ extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, co
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(from->stream));
+    dst->label_version++;
     return GNN_OK;
 }
 

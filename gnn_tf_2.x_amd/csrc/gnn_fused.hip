@@ -176,8 +176,10 @@ int gnn_fused_prepare(gnn_loop *l)
         HIPCHK(hipMalloc((void **)&l->inv, std::max<size_t>(1, (size_t)g->n_rows * IW) * sizeof(float)));
     }
     if (IW == 0) return GNN_OK;
-    // [nodes | Adjacency^T . nodes | ArcNode^T . arc labels]  (GNN.py:263, :259); recomputed per run: labels may have
-    // been rewritten by gnn_graph_update_labels
+    // [nodes | Adjacency^T . nodes | ArcNode^T . arc labels]  (GNN.py:263, :259): loop-invariant, and unchanged from run to run
+    // unless gnn_graph_update_labels rewrote the labels in between (LGNN stacks)
+    if (l->inv_version == g->label_version) return GNN_OK;
+    l->inv_version = g->label_version;
     int rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL,
                              l->inv + 2 * l->NLc, IW, nullptr, 1);
     if (rc) return rc;
