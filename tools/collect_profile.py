@@ -1,0 +1,31 @@
+"""Copies the judged pieces of a tools/profile.sh run (gpurun_out/prof_<tag>/ + gpurun_out/bench_<tag>.json) into profiles/:
+the rocprofv3 summary, the kernel stats, the bench line and the HBM traffic of the default fused kernel (FETCH_SIZE doubled
+as MI355X_MICROARCH.md prescribes for gfx950 16-byte-per-lane reads, WRITE_SIZE as is)."""
+import collections, csv, json, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+d = f'gpurun_out/prof_{tag}/'
+
+
+def pmc(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+
+
+f, w = pmc(d + 'pmc_fetch/pmc_counter_collection.csv'), pmc(d + 'pmc_write/pmc_counter_collection.csv')
+k = [n for n in f if 'k_fused' in n and 'true' in n][0]
+avg = lambda a: sum(a) / len(a)
+fetch, write = avg(f[k]['FETCH_SIZE']), avg(w[k]['WRITE_SIZE'])
+out = json.load(open(f'profiles/{tag}_traffic.json'))
+out.update({'kernel': k, 'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write, 'TCC_HIT_per_launch': avg(w[k]['TCC_HIT_sum']),
+            'TCC_MISS_per_launch': avg(w[k]['TCC_MISS_sum']), 'hbm_bytes_per_launch': 2 * fetch * 1024 + write * 1024,
+            'launches_averaged': len(f[k]['FETCH_SIZE'])})
+json.dump(out, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
+shutil.copy(d + 'summary.txt', f'profiles/{tag}_rocprofv3_summary.txt')
+shutil.copy(d + 'stats/stats_kernel_stats.csv', f'profiles/{tag}_kernel_stats.csv')
+shutil.copy(f'gpurun_out/bench_{tag}.json', f'profiles/{tag}_bench_1gpu.json')
+for r in list(csv.DictReader(open(d + 'stats/stats_kernel_stats.csv')))[:3]:
+    print(r['Name'][:70], r['Calls'], r['AverageNs'])
+print('hbm bytes per launch', out['hbm_bytes_per_launch'])
