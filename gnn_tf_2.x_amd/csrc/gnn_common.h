@@ -133,6 +133,7 @@ struct gnn_mlp {
     size_t packed_floats = 0;
     int *packed_split = nullptr;        // bf16-piece weight image of the split-arithmetic fused kernel (impl 2)
     size_t packed_split_dwords = 0;
+    bool pack_dirty = true;             // the images are rebuilt on the next fused use (training rewrites the weights every step)
     uint64_t version = 0;
 };
 

@@ -753,7 +753,8 @@ static int mlp_upload(gnn_mlp *m, const float *const *W, const float *const *b, 
         HIPCHK(hipMemcpy(m->bn_shift, sh.data(), sizeof(float) * f, hipMemcpyHostToDevice));
     }
     m->version++;
-    return gnn_fused_pack(m);
+    m->pack_dirty = true;       // packed images of the fused kernel: rebuilt lazily (gnn_fused_supported)
+    return GNN_OK;
 }
 
 extern "C" int gnn_mlp_create(int n_layers, const int32_t *dims, const int32_t *acts, const float *const *W,

@@ -160,7 +160,12 @@ void gnn_fused_release(gnn_mlp *m)
 bool gnn_fused_supported(const gnn_loop *l)
 {
     FusedPlan p;
-    if (!l->st->packed || !make_plan(l->st, p)) return false;
+    if (!make_plan(l->st, p)) return false;
+    if (l->st->pack_dirty) {            // weights changed since the images were built
+        if (gnn_fused_pack(l->st) != GNN_OK) return false;
+        l->st->pack_dirty = false;
+    }
+    if (!l->st->packed) return false;
     if (lds_bytes(p) > 160 * 1024) return false;                            // one 8-wave workgroup per CU
     const int Ds = l->Ds;
     if (!((Ds % 4 == 0 && Ds <= 256) || Ds <= 64)) return false;           // one column chunk per lane in the gather

@@ -72,8 +72,9 @@ __global__ void k_act_fwd(int64_t n, int F, const float *z, int act, float *a)
     }
 }
 
-// dz = da * act'(z) (softmax: a * (da - sum da a) per row); in place on d
-__global__ void k_act_bwd(int64_t n, int F, float *d, const float *z, const float *a, int act)
+// dz = da * act'(z) (softmax: a * (da - sum da a) per row); in place on d.  Every derivative is a function of the OUTPUT a
+// alone (selu: z > 0 <=> a > 0 and scale * alpha * e^z = a + scale * alpha; elu: e^z = a + 1), so z is not kept.
+__global__ void k_act_bwd(int64_t n, int F, float *d, const float *a, int act)
 {
     if (act == GNN_ACT_SOFTMAX) {
         const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,12 +86,12 @@ __global__ void k_act_bwd(int64_t n, int F, float *d, const float *z, const floa
     }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * F) return;
-    const float zz = z[i], aa = a[i];
+    const float aa = a[i];
     float g;
     switch (act) {
-    case GNN_ACT_RELU: g = zz > 0.0f ? 1.0f : 0.0f; break;
-    case GNN_ACT_SELU: g = zz > 0.0f ? 1.0507009873554805f : 1.0507009873554805f * 1.6732632423543772f * gnn_expf(zz); break;
-    case GNN_ACT_ELU: g = zz > 0.0f ? 1.0f : gnn_expf(zz); break;
+    case GNN_ACT_RELU: g = aa > 0.0f ? 1.0f : 0.0f; break;
+    case GNN_ACT_SELU: g = aa > 0.0f ? 1.0507009873554805f : aa + 1.0507009873554805f * 1.6732632423543772f; break;
+    case GNN_ACT_ELU: g = aa > 0.0f ? 1.0f : aa + 1.0f; break;
     case GNN_ACT_TANH: g = 1.0f - aa * aa; break;
     case GNN_ACT_SIGMOID: g = aa * (1.0f - aa); break;
     default: g = 1.0f; break;
@@ -251,7 +252,7 @@ __global__ void k_transpose(int ni, int no, const float *W, float *WT)
 }
 
 struct NetCache {                 // what one training-mode forward of a Sequential leaves for the backward pass
-    std::vector<float *> hin, z, a;
+    std::vector<float *> hin, a;
     std::vector<uint8_t *> keep;  // per dropout index 0..L (nullptr when no dropout there)
     float *xhat = nullptr, *stats = nullptr;
     int64_t n = 0;
@@ -262,6 +263,7 @@ struct Net {
     std::vector<float *> WT;      // W^T per layer
     float *gamma = nullptr, *beta = nullptr;
     std::vector<float> rate;      // [L + 1] dropout rate in front of Dense l (index L: in front of BatchNormalization)
+    float *zero = nullptr;        // zero "bias" of the d h = d z . W^T products (max layer input width)
     float *grads = nullptr;       // flat: dW1, db1, ..., dgamma, dbeta
     std::vector<size_t> g_off;
     size_t g_total = 0;
@@ -293,9 +295,12 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
         net.g_off.push_back(off); off += F;
     }
     net.g_total = off;
-    int rc = buf.get(&net.grads, off);
+    int maxw = 1;
+    for (int l = 0; l <= L; ++l) maxw = std::max(maxw, m->dims[l]);
+    int rc = buf.get(&net.grads, off + maxw);         // gradients, then the zero vector: one memset
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(net.grads, 0, off * sizeof(float), st));
+    net.zero = net.grads + off;
+    HIPCHK(hipMemsetAsync(net.grads, 0, (off + maxw) * sizeof(float), st));
     return GNN_OK;
 }
 
@@ -305,7 +310,7 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
     c.n = n;
-    c.hin.assign(L, nullptr); c.z.assign(L, nullptr); c.a.assign(L, nullptr); c.keep.assign(L + 1, nullptr);
+    c.hin.assign(L, nullptr); c.a.assign(L, nullptr); c.keep.assign(L + 1, nullptr);
     float *h = x;
     size_t mask_off = 0;
     int rc;
@@ -325,11 +330,11 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
         if (l == L) break;
         const int no = m->dims[l + 1];
         c.hin[l] = h;
-        if ((rc = buf.get(&c.z[l], (size_t)n * no)) || (rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
-        if ((rc = gnn_launch_dense(st, n, width, no, h, width, m->W[l], m->b[l], GNN_ACT_LINEAR, c.z[l], no))) return rc;
-        if (n > 0) {
-            const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;
-            hipLaunchKernelGGL(k_act_fwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, c.z[l], m->acts[l], c.a[l]);
+        if ((rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
+        const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;          // softmax needs the whole row: separate pass, in place
+        if ((rc = gnn_launch_dense(st, n, width, no, h, width, m->W[l], m->b[l], sm ? GNN_ACT_LINEAR : m->acts[l], c.a[l], no))) return rc;
+        if (n > 0 && sm) {
+            hipLaunchKernelGGL(k_act_fwd, cdiv(n, 256), 256, 0, st, n, no, c.a[l], m->acts[l], c.a[l]);
             HIPCHK(hipGetLastError());
         }
         h = c.a[l];
@@ -390,18 +395,15 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         if ((rc = buf.get(&dprev, (size_t)n * ni))) return rc;
         if (n > 0) {
             const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;
-            hipLaunchKernelGGL(k_act_bwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, d, c.z[l], c.a[l], m->acts[l]);
+            hipLaunchKernelGGL(k_act_bwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, d, c.a[l], m->acts[l]);
             dim3 gw(cdiv(ni, 16), cdiv(no, 16), cdiv(n, rpb));
             hipLaunchKernelGGL(k_wgrad, gw, 256, 0, st, n, ni, no, c.hin[l], d, net.grads + net.g_off[2 * l], rpb);
             dim3 gb(cdiv(no, 32), cdiv(n, rpb));
             hipLaunchKernelGGL(k_colreduce, gb, 256, 0, st, n, no, d, (const float *)nullptr, (const float *)nullptr, 0, net.grads + net.g_off[2 * l + 1], (float *)nullptr, rpb);
             HIPCHK(hipGetLastError());
         }
-        // d h_in = d z . W^T  (bias-free: reuse the zero tail of the gradient buffer? no: a dedicated zero vector)
-        float *zero = nullptr;
-        if ((rc = buf.get(&zero, (size_t)ni))) return rc;
-        HIPCHK(hipMemsetAsync(zero, 0, sizeof(float) * ni, st));
-        if ((rc = gnn_launch_dense(st, n, no, ni, d, no, net.WT[l], zero, GNN_ACT_LINEAR, dprev, ni))) return rc;
+        // d h_in = d z . W^T  (bias-free: the zero vector behind the gradients)
+        if ((rc = gnn_launch_dense(st, n, no, ni, d, no, net.WT[l], net.zero, GNN_ACT_LINEAR, dprev, ni))) return rc;
         if (net.rate[l] > 0.0f && n > 0) {
             hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * ni, 256), 256, 0, st, n * ni, c.keep[l], net.rate[l], dprev);
             HIPCHK(hipGetLastError());

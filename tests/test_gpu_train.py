@@ -47,11 +47,15 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
     targets = np.eye(2)[rng.integers(0, 2, n_t)].astype(np.float32)
     weights = rng.uniform(0.5, 1.5, n_t).astype(np.float32)
     s0 = (0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None
-    ref = tro.train_step(g, st, ou, d, max_it, 0.05, s0, masks_s, masks_o, targets, weights, loss=loss, mean=False, graph_based=graph_based)
+    # threshold 0: the training-mode forward has BatchNormalization batch statistics accumulated with float atomics, whose last
+    # bits vary from run to run; a borderline convergence test could then stop one body earlier or later than the float64 oracle.
+    # The early stop itself is covered by test_training_forward_stops_at_convergence (no BatchNormalization: deterministic).
+    thr = 0.0
+    ref = tro.train_step(g, st, ou, d, max_it, thr, s0, masks_s, masks_o, targets, weights, loss=loss, mean=False, graph_based=graph_based)
 
     graph = e.Graph(n, g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], np.asarray(g['arcs'])[:, 2:][g['arcT'][1]], nodes, mask)
     mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
-    loop = e.Loop(graph, mst, mou, d, max_it, 0.05)
+    loop = e.Loop(graph, mst, mou, d, max_it, thr)
     if d:
         loop.set_state0(s0)
     ms = np.concatenate([masks_s[k][0].astype(np.uint8).ravel() for k in range(max_it)])
@@ -458,3 +462,36 @@ def test_regularizers_join_the_device_gradients():
     np.testing.assert_allclose(b['grads_state'][0], a['grads_state'][0] + 0.1 * w[0], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(b['grads_state'][1], a['grads_state'][1], rtol=1e-5, atol=1e-6)          # bias of net_state: no regularizer
     np.testing.assert_allclose(b['grads_output'][1], a['grads_output'][1] + 0.1 * plain.net_output.get_weights()[1], rtol=1e-5, atol=1e-6)
+
+
+
+def test_training_forward_stops_at_convergence():
+    """The while-condition of the training-mode Loop (GNN.py:271) with a contractive net and no BatchNormalization / Dropout:
+    deterministic on the device, so the executed bodies must equal the float64 oracle's, and be fewer than max_iteration."""
+    from GNN import _engine as e
+    rng = np.random.default_rng(17)
+    n, nl, al, d, max_it = 300, 3, 2, 6, 30
+    arcs = random_arcs(rng, n, 900, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    st = make_mlp(rng, al + 2 * (d + nl), [10, d], 'tanh', gain=0.5)
+    ou = make_mlp(rng, d + nl, [2], 'tanh', out_activation='softmax')
+    for net in (st, ou):
+        net.update(batch_normalization=False, weights=net['weights'][:-4], dropout={})
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    targets = np.eye(2)[rng.integers(0, 2, n)].astype(np.float32)
+    weights = np.ones(n, np.float32)
+    ref = tro.train_step(g, st, ou, d, max_it, 0.02, s0, [{}] * max_it, {}, targets, weights, mean=True)
+    assert 2 <= ref['k'] < max_it
+    graph = e.Graph(n, g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], np.asarray(g['arcs'])[:, 2:][g['arcT'][1]], nodes, np.ones(n, np.uint8))
+    mst, mou = e.Mlp(st['weights'], st['activations'], False), e.Mlp(ou['weights'], ou['activations'], False)
+    loop = e.Loop(graph, mst, mou, d, max_it, 0.02)
+    loop.set_state0(s0)
+    res = loop.train_step(mst, mou, None, targets, weights, 0, max_iter=max_it)
+    assert res['k'] == ref['k']
+    assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    k = ref['k']
+    for got, want in zip(res['grads_state'], ref['grads_state']):      # the oracle divided by k (mean=True); the device returns raw sums
+        assert np.max(np.abs(got / k - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want)))
+    for got, want in zip(res['grads_output'], ref['grads_output']):
+        assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want)))

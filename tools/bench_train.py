@@ -19,13 +19,20 @@ ou = MLP(14, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False
 gnn = GNNgraphBased(net_state=st, net_output=ou, optimizer=optimizers.Adam(0.001), loss_function=losses.categorical_crossentropy, loss_arguments=None,
                     state_vect_dim=0, max_iteration=10, threshold=0.001, addressed_problem='c')
 for b in batches: gnn.training_step(b, True)
+from GNN import _engine as _e
+_orig = _e.Loop.train_step
+_acc = [0.0]
+def _timed(self, *a, **k):
+    t0 = time.perf_counter(); r = _orig(self, *a, **k); _acc[0] += time.perf_counter() - t0; return r
+_e.Loop.train_step = _timed
 t = time.perf_counter(); n = 0
 for _ in range(10):
     for b in batches:
         r = gnn.training_step(b, True); n += 1
 print('  last k', r['k'], 'loss', r['loss'])
 dt = time.perf_counter() - t
-print(f'MUTAG batch-32 training_step: {1e3 * dt / n:.2f} ms/step  (k={r["k"]}), {32 * n / dt:.0f} graphs/s')
+print(f'MUTAG batch-32 training_step: {1e3 * dt / n:.2f} ms/step  (k={r["k"]}), {32 * n / dt:.0f} graphs/s; inside gnn_loop_train_step: {1e3 * _acc[0] / n:.2f} ms')
+_acc[0] = 0.0
 
 if os.environ.get("SMALL_ONLY"): sys.exit(0)
 N = 100_000
