@@ -495,3 +495,4 @@ def test_training_forward_stops_at_convergence():
         assert np.max(np.abs(got / k - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want)))
     for got, want in zip(res['grads_output'], ref['grads_output']):
         assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want)))
+
