@@ -140,18 +140,20 @@ __device__ __forceinline__ float act_fast(float v)
 
 // bias + activation (+ BatchNormalization when BN) on one accumulator tile; feature of register r on this lane:
 // 32 jt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-template <int ACT, bool BN, bool FAST = false>
+// LDS: the three vectors were staged in LDS at kernel start (last layer of the tile loop: no global round trips per tile)
+template <int ACT, bool BN, bool FAST = false, bool LDS = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, const float *bn_scale, const float *bn_shift,
                                               int jt, int half)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int f0 = 32 * jt + 8 * q + 4 * half;
-        const v4f b = gload4(bias + f0);
+        const v4f b = LDS ? *reinterpret_cast<const v4f *>(bias + f0) : gload4(bias + f0);
         const float bb[4] = {b.x, b.y, b.z, b.w};
         float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
         if (BN) {
-            const v4f s4 = gload4(bn_scale + f0), h4 = gload4(bn_shift + f0);
+            const v4f s4 = LDS ? *reinterpret_cast<const v4f *>(bn_scale + f0) : gload4(bn_scale + f0);
+            const v4f h4 = LDS ? *reinterpret_cast<const v4f *>(bn_shift + f0) : gload4(bn_shift + f0);
             sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
             sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
         }
@@ -831,6 +833,13 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     const int KP = a.KP, Ds = a.Ds, NLc = a.NLc;
     float *X = lds + (size_t)wave * 32 * KP;
     const int c_aggs = Ds + NLc;                      // column of the aggregated state block
+    // last-layer bias and BatchNormalization scale / shift: staged once per workgroup behind the row-pointer slots
+    float *ep = lds + (size_t)GNN_FUSED_WAVES * 32 * KP + 32 + GNN_FUSED_WAVES * 36;
+    for (int t = threadIdx.x; t < 3 * 32 * NTL; t += GNN_FUSED_THREADS) {
+        const int which = t / (32 * NTL), f = t - which * 32 * NTL;
+        ep[t] = which == 0 ? a.bias[LAYERS - 1][f] : (a.bn_scale ? (which == 1 ? a.bn_scale[f] : a.bn_shift[f]) : 0.0f);
+    }
+    __syncthreads();
     if (wave >= GNN_FUSED_WAVES / 2)
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     int tile = 0;
@@ -920,8 +929,8 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     GNN_STAMP(5);
 #pragma unroll
     for (int jt = 0; jt < NTL; ++jt) {
-        if (a.bn_scale) tile_epilogue<ACT, true, SPLIT>(out[jt], a.bias[LAYERS - 1], a.bn_scale, a.bn_shift, jt, half);
-        else tile_epilogue<ACT, false, SPLIT>(out[jt], a.bias[LAYERS - 1], nullptr, nullptr, jt, half);
+        if (a.bn_scale) tile_epilogue<ACT, true, SPLIT, true>(out[jt], ep, ep + 32 * NTL, ep + 64 * NTL, jt, half);
+        else tile_epilogue<ACT, false, SPLIT, true>(out[jt], ep, nullptr, nullptr, jt, half);
         float *x = X + (lane & 31) * KP + c_aggs;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
