@@ -74,8 +74,8 @@ bool make_plan(const gnn_mlp *m, FusedPlan &p)
 // GNN_FUSED_WAVES wave tiles [32][KP], 128 B of slack (the layer-0 pipeline reads two groups past the last tile), GNN_FUSED_WAVES x 36 row pointers
 size_t lds_bytes(const FusedPlan &p)
 {
-    // ... and the last layer's bias / BatchNormalization scale / shift (3 x 32 NTL floats, 16-byte aligned: KP is odd, so pad)
-    return (size_t)GNN_FUSED_WAVES * 32 * p.KP * sizeof(float) + 128 + GNN_FUSED_WAVES * 36 * sizeof(int) + 3 * 32 * 4 * sizeof(float) + 16;
+    // ... and the last layer's bias / BatchNormalization scale / shift (3 x 32 NTL floats) and the hidden biases (2 x 32 NT)
+    return (size_t)GNN_FUSED_WAVES * 32 * p.KP * sizeof(float) + 128 + GNN_FUSED_WAVES * 36 * sizeof(int) + (3 + 2) * 32 * 4 * sizeof(float) + 16;
 }
 
 }   // namespace

@@ -418,7 +418,8 @@ __device__ __forceinline__ void layer0_split(const float *xr, const int *wl, int
 #undef GNN_S0_MFMA
 }
 
-// hidden / last layer: input = accumulator tiles of the previous layer; its epilogue (bias + activation) is applied here,
+// hidden / last layer: input = accumulator tiles of the previous layer; its epilogue (bias + activation; bias_prev points to the
+// copy staged in LDS at kernel start) is applied here,
 // software-pipelined in program order against this layer's MFMAs (the wave issues in order; VALU work placed right after
 // an MFMA runs while the matrix pipe executes it): while the 6 NO MFMAs of chunk c are issued, the 8 elements of chunk
 // c + 2 get bias + activation (E) and the elements of chunk c + 1 are cut into bf16 pieces (S), one task per few MFMAs.
@@ -440,8 +441,8 @@ __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const f
             w[UU][t][pc] = gload4i(wl + (size_t)((((UU) / UPC) * NO + ((UU) % UPC) * TPU + t) * 3 + pc) * 256);
 #define GNN_S1_BIAS(C, DST)                                                                         \
     {                                                                                               \
-        const v4f q0 = gload4(bias_prev + 32 * ((C) >> 1) + 16 * ((C) & 1) + 4 * half);             \
-        const v4f q1 = gload4(bias_prev + 32 * ((C) >> 1) + 16 * ((C) & 1) + 8 + 4 * half);         \
+        const v4f q0 = *reinterpret_cast<const v4f *>(bias_prev + 32 * ((C) >> 1) + 16 * ((C) & 1) + 4 * half);      \
+        const v4f q1 = *reinterpret_cast<const v4f *>(bias_prev + 32 * ((C) >> 1) + 16 * ((C) & 1) + 8 + 4 * half);  \
         DST[0] = q0.x; DST[1] = q0.y; DST[2] = q0.z; DST[3] = q0.w;                                 \
         DST[4] = q1.x; DST[5] = q1.y; DST[6] = q1.z; DST[7] = q1.w;                                 \
     }
@@ -839,6 +840,9 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
         const int which = t / (32 * NTL), f = t - which * 32 * NTL;
         ep[t] = which == 0 ? a.bias[LAYERS - 1][f] : (a.bn_scale ? (which == 1 ? a.bn_scale[f] : a.bn_shift[f]) : 0.0f);
     }
+    float *hb = ep + 3 * 32 * NTL;                    // hidden-layer biases (split path): [LAYERS - 1][32 NT]
+    if constexpr (SPLIT && LAYERS > 1)
+        for (int t = threadIdx.x; t < (LAYERS - 1) * 32 * NT; t += GNN_FUSED_THREADS) hb[t] = a.bias[t / (32 * NT)][t % (32 * NT)];
     __syncthreads();
     if (wave >= GNN_FUSED_WAVES / 2)
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
@@ -897,11 +901,11 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
             GNN_STAMP(3);
             GNN_STAMP(4);
             if constexpr (LAYERS == 2) {
-                layer_split_from_regs<NT, NTL, ACT>(h1, a.bias[0], half, out, a.Ws[1] + 4 * lane);
+                layer_split_from_regs<NT, NTL, ACT>(h1, hb, half, out, a.Ws[1] + 4 * lane);
             } else {
                 f32x16 h2[NT];
-                layer_split_from_regs<NT, NT, ACT>(h1, a.bias[0], half, h2, a.Ws[1] + 4 * lane);
-                layer_split_from_regs<NT, NTL, ACT>(h2, a.bias[1], half, out, a.Ws[2] + 4 * lane);
+                layer_split_from_regs<NT, NT, ACT>(h1, hb, half, h2, a.Ws[1] + 4 * lane);
+                layer_split_from_regs<NT, NTL, ACT>(h2, hb + 32 * NT, half, out, a.Ws[2] + 4 * lane);
             }
         }
     } else if constexpr (LAYERS == 1) {
