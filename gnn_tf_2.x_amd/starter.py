@@ -95,14 +95,19 @@ def _nets(net_name, hidden, activations, kinit, binit, drate, dpos):
     dims = [get_inout_dims(net_name=net_name, dim_node_label=gGen.DIM_NODE_LABEL, dim_arc_label=gGen.DIM_ARC_LABEL,
                            dim_target=gGen.DIM_TARGET, problem_based=problem_based, dim_state=dim_state, hidden_units=hidden,
                            layer=i, get_state=get_state, get_output=get_output) for i in range(layers)]
+    # MLP's default BatchNormalization after the LAST layer applies to net_output too, as in the reference (MLP.py:13, :63): with a
+    # 2-class softmax the two normalised columns are exact opposites, categorical_crossentropy then renormalises by a sum of ~0 and
+    # clips, and no gradient reaches the weights - the reference's default behaves the same.  GNN_STARTER_OUTPUT_BN=0 turns that
+    # layer off for net_output (what tools/run_starter.py does to show the training loop learning).
+    bn = net_name != 'output' or os.environ.get('GNN_STARTER_OUTPUT_BN', '1') != '0'
     return [MLP(input_dim=i, layers=j, activations=activations, kernel_initializer=kinit, bias_initializer=binit,
-                dropout_rate=drate, dropout_pos=dpos) for i, j in dims]
+                dropout_rate=drate, dropout_pos=dpos, batch_normalization=bn) for i, j in dims]
 
 nets_St = _nets('state', hidden_units_net_state, activations_net_state, kernel_init_net_state, bias_init_net_state, dropout_rate_st, dropout_pos_st)
 nets_Out = _nets('output', hidden_units_net_output, activations_net_output, kernel_init_net_output, bias_init_net_output, dropout_rate_out, dropout_pos_out)
 
 gnntype = {'n': GNNnodeBased, 'a': GNNedgeBased, 'g': GNNgraphBased}[problem_based]
-gnns = [gnntype(net_state=st, net_output=out, optimizer=optimizer, loss_function=lossF, loss_arguments=lossArguments,
+gnns = [gnntype(net_state=st, net_output=out, optimizer=optimizer.__class__(**optimizer.get_config()), loss_function=lossF, loss_arguments=lossArguments,
                 state_vect_dim=dim_state, max_iteration=max_iter, threshold=state_threshold, addressed_problem=addressed_problem,
                 extra_metrics=extra_metrics, extra_metrics_arguments=metrics_args, path_writer=f'{path_writer}/GNN{idx}')
         for idx, (st, out) in enumerate(zip(nets_St, nets_Out))]
