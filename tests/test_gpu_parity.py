@@ -552,3 +552,31 @@ def test_edge_based_lgnn_stack_on_device(get_state, get_output):
     # host form of update_graph agrees with the oracle's
     upd = lgnn.update_graph(__import__('GNN.graph_class', fromlist=['GraphTensor']).GraphTensor.fromGraphObject(go), sc, oc)
     assert np.array_equal(upd.nodes, gtmp['nodes']) and np.array_equal(upd.arcs, gtmp['arcs'])
+
+
+def test_fast_path_on_skewed_degrees():
+    """The Ds == 64 full-tile gather (batches of 16 entries per 16-lane group, row-boundary flushes, tail batches) on a degree
+    distribution it was not tuned for: hubs with thousands of in-arcs, long runs of isolated nodes, rows of exactly 16 / 17 entries."""
+    rng = np.random.default_rng(99)
+    n, d, nl, al = 2048, 64, 3, 1
+    deg = np.zeros(n, np.int64)
+    deg[rng.choice(n, 6, replace=False)] = rng.integers(1500, 4000, 6)          # hubs
+    body = rng.choice(n, 900, replace=False)
+    deg[body] = np.maximum(deg[body], rng.integers(1, 40, 900))
+    deg[100:132] = 16; deg[132:164] = 17; deg[164:260] = 0                       # whole tiles of 16s, 17s and isolated nodes
+    dst = np.repeat(np.arange(n), deg)
+    src = rng.integers(0, n, len(dst))
+    keep = src != dst
+    pairs = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)               # (src, dst)-sorted, duplicate free
+    arcs = np.concatenate([pairs.astype(np.float32), (2 * rng.random((len(pairs), al)) - 1).astype(np.float32)], axis=1)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    g['set_mask'] = rng.random(n) < 0.9
+    st, ou = make_mlp(rng, al + 2 * (nl + d), [128, 128, d], 'selu', gain=0.6), make_mlp(rng, nl + d, [2], 'softmax')
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 12, 0.01, s0)
+    for impl in (1, 0):
+        k, s, o = _run_hip(g, st, ou, d, 12, 0.01, s0, impl)
+        assert k == kc and np.array_equal(s, sc) and np.array_equal(o, oc), impl
+    k, s, o = _run_hip(g, st, ou, d, 12, 0.01, s0, 2)
+    assert k == kc and np.max(np.abs(s - sc)) < 2e-6 * max(1.0, float(np.max(np.abs(sc)))) and np.max(np.abs(o - oc)) < 2e-6
