@@ -580,3 +580,22 @@ def test_fast_path_on_skewed_degrees():
         assert k == kc and np.array_equal(s, sc) and np.array_equal(o, oc), impl
     k, s, o = _run_hip(g, st, ou, d, 12, 0.01, s0, 2)
     assert k == kc and np.max(np.abs(s - sc)) < 2e-6 * max(1.0, float(np.max(np.abs(sc)))) and np.max(np.abs(o - oc)) < 2e-6
+
+
+@pytest.mark.parametrize('d,hidden,expect_fused', [(60, (128,), True), (68, (96,), True), (128, (128,), False), (66, (64,), False), (16, (200,), False)])
+def test_wide_states_and_fallback(d, hidden, expect_fused):
+    """State widths around the tuned shape: Ds = 60 / 68 run fused through the generic gather (68: three feature tiles of state),
+    Ds = 128 (the concat no longer fits eight LDS tiles), Ds = 66 (neither a multiple of 4 nor <= 64) and a hidden width above
+    128 fall back to the per-op kernels - same bits either way."""
+    e = _engine()
+    rng = np.random.default_rng(300 + d)
+    g, st, ou, s0 = _case(rng, n=333, d=d, nl=3, al=2, hidden=hidden, act='tanh', gain=0.5)
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 10, 0.01, s0)
+    loop = e.Loop(_device_graph(g), e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), d, 10, 0.01)
+    assert (loop.set_impl(1) == 1) == expect_fused
+    loop.set_state0(s0)
+    k = loop.run()
+    assert k == kc and np.array_equal(loop.state(), sc) and np.array_equal(loop.output(), oc)
+    assert (loop.set_impl(2) == 2) == expect_fused
+    k = loop.run()
+    assert k == kc and np.max(np.abs(loop.state() - sc)) < 2e-6 * max(1.0, float(np.max(np.abs(sc))))
