@@ -26,6 +26,19 @@ json.dump(out, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
 shutil.copy(d + 'summary.txt', f'profiles/{tag}_rocprofv3_summary.txt')
 shutil.copy(d + 'stats/stats_kernel_stats.csv', f'profiles/{tag}_kernel_stats.csv')
 shutil.copy(f'gpurun_out/bench_{tag}.json', f'profiles/{tag}_bench_1gpu.json')
+# per-Loop means of the default kernel from the kernel trace: bench.py times only its `--steps` Loops with HIP events, while the
+# rocprofv3 mean over all launches also contains the warm-up Loop, the PCIe-inclusive Loop and the one-body launch
+rows = [r for r in csv.DictReader(open(d + 'stats/stats_kernel_trace.csv')) if r['Kernel_Name'] == k]
+dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows]
+loops = [dur[i:i + 30] for i in range(0, len(dur) - len(dur) % 30, 30)]
+with open(f'profiles/{tag}_fused_kernel_per_loop.txt', 'w') as fo:
+    fo.write(f'{k}\n{len(dur)} launches in the rocprofv3 kernel trace of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`, mean {sum(dur) / len(dur):.4f} ms\n')
+    names = ['warm-up Loop', 'timed step 1', 'timed step 2', 'PCIe-inclusive Loop']
+    for i, l in enumerate(loops):
+        fo.write(f'Loop {i} ({names[i] if i < len(names) else "extra"}): mean of its 30 launches {sum(l) / len(l):.4f} ms, min {min(l):.4f}, max {max(l):.4f}\n')
+    fo.write(f'remaining launches (one-body comparison run): {[round(x, 4) for x in dur[len(loops) * 30:]]}\n')
+    fo.write('bench.py reports the HIP-event mean over the timed steps only (roofline.avg_launch_ms).\n')
+print(open(f'profiles/{tag}_fused_kernel_per_loop.txt').read())
 for r in list(csv.DictReader(open(d + 'stats/stats_kernel_stats.csv')))[:3]:
     print(r['Name'][:70], r['Calls'], r['AverageNs'])
 print('hbm bytes per launch', out['hbm_bytes_per_launch'])
