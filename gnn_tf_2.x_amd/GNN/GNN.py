@@ -95,11 +95,15 @@ class GNNnodeBased(BaseClass):
     def _device_loop(self, dev_graph: _engine.Graph) -> _engine.Loop:
         """One gnn_loop per (this model, device graph), created on first use."""
         cache = dev_graph.__dict__.setdefault('_loops', {})
-        owner, loop = cache.get(id(self), (None, None))
+        # the C loop is configured once: a changed max_iteration / state_threshold / state_vect_dim needs a new one
+        key = (id(self), int(self.max_iteration), float(self.state_threshold), int(self.state_vect_dim))
+        owner, loop = cache.get(key, (None, None))
         if owner is None or owner() is not self:
+            for old in [k for k in cache if k[0] == id(self)]:
+                del cache[old]
             loop = _engine.Loop(dev_graph, self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device),
                                 self.state_vect_dim, self.max_iteration, self.state_threshold)
-            cache[id(self)] = (weakref.ref(self), loop)
+            cache[key] = (weakref.ref(self), loop)
         loop.set_impl(self.impl)
         return loop
 
@@ -151,7 +155,7 @@ class GNNnodeBased(BaseClass):
                               kind, g.nodegraph_csr() if self._graph_based else None, dropout_state=self.net_state.dropout_rates(),
                               dropout_output=self.net_output.dropout_rates(), masks_state=masks_state, masks_output=masks_output,
                               seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),
-                              bn_output=self.net_output.bn_gamma_beta(), max_iter=self.max_iteration)
+                              bn_output=self.net_output.bn_gamma_beta())
         k = res['k']
         # regularizer terms are part of the taped loss (reference GNN_BaseClass.py:223-235): their gradients join the device ones
         from GNN import regularizers

@@ -20,7 +20,8 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loss_grad',
            'gnn_loop_set_impl', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
-           'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy']
+           'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
+           'gnn_comm_create_loopback', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
 
 _lib = None
 
@@ -98,6 +99,43 @@ def shard_range(n_nodes: int, rank: int, world: int) -> tuple[int, int]:
     return b.value, n.value
 
 
+def halo_plan(n_nodes: int, world: int, indptr, adj_src):
+    """gnn_halo_plan: (slot [n_nodes] int32, counts [world], block) of the boundary exchange for a whole CSR-by-destination graph."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    adj_src = np.ascontiguousarray(adj_src, dtype=np.int32)
+    slot = np.empty(n_nodes, np.int32)
+    counts = np.zeros(world, np.int64)
+    block = C.c_int64(0)
+    _check(lib().gnn_halo_plan(C.c_int64(n_nodes), C.c_int(world), _ip(indptr), _ip(adj_src), _ip(slot),
+                               counts.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(block)))
+    return slot, counts, int(block.value)
+
+
+def shard_halo(n_nodes: int, rank: int, world: int, indptr, adj_src, nodes, plan=None):
+    """Arguments of Graph.halo for one rank: sources renumbered into the compact index space
+    [own rows | block of boundary rows per rank] and the node labels in the same space."""
+    slot, counts, block = plan if plan is not None else halo_plan(n_nodes, world, indptr, adj_src)
+    rb, nr = shard_range(n_nodes, rank, world)
+    shard = ((n_nodes + world - 1) // world + 31) // 32 * 32
+    indptr = np.asarray(indptr)
+    e0, e1 = int(indptr[rb]), int(indptr[rb + nr])
+    src = np.asarray(adj_src)[e0:e1].astype(np.int64)
+    owner = src // shard
+    mine = owner == rank
+    if np.any(~mine & (slot[src] < 0)):
+        raise ValueError('halo plan does not cover a remote source')
+    remapped = np.where(mine, src - rb, shard + owner * block + slot[src]).astype(np.int32)
+    nodes = np.asarray(nodes, np.float32)
+    rep = np.zeros((shard + world * block, nodes.shape[1]), np.float32)
+    rep[:nr] = nodes[rb:rb + nr]
+    for q in range(world):
+        qb, qn = shard_range(n_nodes, q, world)
+        ids = qb + np.nonzero(slot[qb:qb + qn] >= 0)[0]
+        rep[shard + q * block: shard + q * block + len(ids)] = nodes[ids]
+    send = np.nonzero(slot[rb:rb + nr] >= 0)[0].astype(np.int32)
+    return dict(block=block, send_rows=send, adj_src=remapped, nodes=rep, row_begin=rb, n_rows=nr, e0=e0, e1=e1)
+
+
 def shard_csr(n_nodes: int, rank: int, world: int, indptr, *per_entry_arrays):
     """Node-range shard of a CSR-by-destination graph: (row_begin, n_rows, local indptr, sliced per-entry arrays...).
     Source ids inside the slices stay GLOBAL (every rank keeps a full replica of the state)."""
@@ -130,6 +168,23 @@ class Graph:
                                       _ip(indptr), _ip(adj_src), _fp(adj_w), _fp(arc_w), _fp(arc_labels),
                                       C.c_int(arc_labels.shape[1]), _fp(nodes), C.c_int(nodes.shape[1]),
                                       mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(device), C.byref(self._h)))
+
+    @classmethod
+    def halo(cls, n_nodes_global, rank, world, block, send_rows, indptr, adj_src_replica, adj_w, arc_w, arc_labels, nodes_replica, mask, device=0):
+        """gnn_graph_create_halo: shard whose per-iteration exchange moves only boundary rows (see shard_halo)."""
+        require_device(device)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        adj = np.ascontiguousarray(adj_src_replica, dtype=np.int32)
+        send = np.ascontiguousarray(send_rows, dtype=np.int32)
+        adj_w, arc_w, arc_labels, nodes_replica = _f32(adj_w), _f32(arc_w), _f32(arc_labels), _f32(nodes_replica)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if len(adj_w) != len(adj) or len(arc_w) != len(adj) or arc_labels.shape[0] != len(adj) or len(mask) != len(indptr) - 1:
+            raise ValueError('inconsistent array lengths')
+        h = C.c_void_p()
+        _check(lib().gnn_graph_create_halo(C.c_int64(n_nodes_global), C.c_int(rank), C.c_int(world), C.c_int64(block), C.c_int64(len(send)), _ip(send),
+                                           C.c_int64(len(adj)), _ip(indptr), _ip(adj), _fp(adj_w), _fp(arc_w), _fp(arc_labels), C.c_int(arc_labels.shape[1]),
+                                           _fp(nodes_replica), C.c_int(nodes_replica.shape[1]), mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(device), C.byref(h)))
+        return cls(None, None, None, None, None, None, None, None, _handle=h)
 
     @classmethod
     def from_arcs(cls, n_nodes, arc_src, arc_dst, arc_labels, aggregation_mode, nodes, mask, device=0):
@@ -176,6 +231,13 @@ class Graph:
 
     def update_labels(self, base: 'Graph', loop: 'Loop', get_state: bool, get_output: bool) -> None:
         _check(lib().gnn_graph_update_labels(self._h, base._h, loop._h, C.c_int(bool(get_state)), C.c_int(bool(get_output))))
+
+    @staticmethod
+    def update_labels_group(dsts, bases, loops, get_state: bool, get_output: bool) -> None:
+        """gnn_graph_update_labels_group: the relabelling step for all ranks of a loopback group."""
+        n = len(loops)
+        arr = lambda xs: (C.c_void_p * n)(*[x._h for x in xs])
+        _check(lib().gnn_graph_update_labels_group(arr(dsts), arr(bases), arr(loops), C.c_int(n), C.c_int(bool(get_state)), C.c_int(bool(get_output))))
 
     def nodes(self) -> np.ndarray:
         d = self.dims()
@@ -260,13 +322,24 @@ class Mlp:
 
 
 class Comm:
-    """RCCL communicator (one process per GPU)."""
+    """RCCL communicator (one process per GPU), or one member of an in-process loopback group (Comm.loopback)."""
 
-    def __init__(self, unique_id: bytes, rank: int, world: int, device: int):
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int, _handle=None):
         self._h = C.c_void_p()
         self.rank, self.world = rank, world
+        if _handle is not None:
+            self._h = _handle
+            return
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         _check(lib().gnn_comm_create(buf, C.c_int(rank), C.c_int(world), C.c_int(device), C.byref(self._h)))
+
+    @classmethod
+    def loopback(cls, world: int, device: int = 0) -> list:
+        """gnn_comm_create_loopback: `world` communicators on ONE device (the sharded path on a single GPU; tests only)."""
+        require_device(device)
+        hs = (C.c_void_p * world)()
+        _check(lib().gnn_comm_create_loopback(C.c_int(world), C.c_int(device), hs))
+        return [cls(None, r, world, device, _handle=C.c_void_p(hs[r])) for r in range(world)]
 
     @staticmethod
     def unique_id() -> bytes:
@@ -298,6 +371,7 @@ class Loop:
         self.Ds = state_dim if state_dim else d['NL']
         self.T = int(net_output.dims[-1])
         self.state_dim = state_dim
+        self.max_iter = int(max_iter)
         _check(lib().gnn_loop_create(graph._h, net_state._h, net_output._h, C.c_int(state_dim), C.c_int(max_iter),
                                      C.c_float(threshold), comm._h if comm else None, C.byref(self._h)))
 
@@ -319,7 +393,7 @@ class Loop:
 
     def train_step(self, net_state: 'Mlp', net_output: 'Mlp', src_csr, targets, sample_weights, loss_kind: int, ng_csr=None,
                    dropout_state=None, dropout_output=None, masks_state=None, masks_output=None, seed: int = 0,
-                   bn_state=None, bn_output=None, max_iter: int = 0):
+                   bn_state=None, bn_output=None):
         """gnn_loop_train_step: loss, iteration count, raw gradients (lists shaped like the trainable arrays) and the
         BatchNormalization batch statistics of every call."""
         sip, sdst, sw = (np.ascontiguousarray(src_csr[0], np.int32), np.ascontiguousarray(src_csr[1], np.int32), _f32(src_csr[2])) if src_csr is not None else (None, None, None)
@@ -340,7 +414,7 @@ class Loop:
         gs = np.zeros(sum(int(np.prod(x)) for x in shp_s), np.float32)
         go = np.zeros(sum(int(np.prod(x)) for x in shp_o), np.float32)
         fs, fo = int(net_state.dims[-1]), int(net_output.dims[-1])
-        bns = np.zeros((max(1, max_iter), 2, fs), np.float32)
+        bns = np.zeros((max(1, self.max_iter), 2, fs), np.float32)      # the C side writes k <= max_iteration rows
         bno = np.zeros((2, fo), np.float32)
         ms = np.ascontiguousarray(masks_state, np.uint8) if masks_state is not None else None
         mo = np.ascontiguousarray(masks_output, np.uint8) if masks_output is not None else None
@@ -441,6 +515,27 @@ class Loop:
         k = C.c_float(0)
         _check(lib().gnn_loop_run(self._h, C.c_int(bool(training)), C.byref(k)))
         return float(k.value)
+
+    @staticmethod
+    def run_group(loops) -> float:
+        """gnn_loop_run_group: one Loop on all ranks of a loopback group (rank order)."""
+        n = len(loops)
+        hs = (C.c_void_p * n)(*[l._h for l in loops])
+        k = C.c_float(0)
+        _check(lib().gnn_loop_run_group(hs, C.c_int(n), C.byref(k)))
+        return float(k.value)
+
+    @staticmethod
+    def readout_group(loops, ng_indptr, ng_node, ng_w) -> np.ndarray:
+        n = len(loops)
+        hs = (C.c_void_p * n)(*[l._h for l in loops])
+        ng_indptr = np.ascontiguousarray(ng_indptr, dtype=np.int32)
+        ng_node = np.ascontiguousarray(ng_node, dtype=np.int32)
+        ng_w = _f32(ng_w)
+        g = len(ng_indptr) - 1
+        out = np.empty((g, loops[0].T), dtype=np.float32)
+        _check(lib().gnn_loop_readout_group(hs, C.c_int(n), C.c_int(g), _ip(ng_indptr), _ip(ng_node), _fp(ng_w), _fp(out)))
+        return out
 
     def timing(self):
         tot, avg, n = C.c_float(), C.c_float(), C.c_int()

@@ -122,7 +122,7 @@ extern "C" int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const
     HIPCHK(hipMemset(d_indeg, 0, sizeof(int32_t) * (N + 1)));
 
     gnn_graph *g = new gnn_graph();
-    g->device = device; g->N = N; g->row_begin = 0; g->n_rows = N; g->E = E;
+    g->device = device; g->N = N; g->N_global = N; g->nodes_rows = N; g->row_begin = 0; g->own_off = 0; g->n_rows = N; g->E = E;
     g->NL = dim_node_label; g->AL = AL; g->base_NL = dim_node_label; g->base_AL = AL;
     g->sh = new gnn_graph_shared();
     gnn_graph_shared *sh = g->sh;

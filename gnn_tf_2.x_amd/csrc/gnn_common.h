@@ -107,8 +107,16 @@ struct gnn_graph_shared {
 
 struct gnn_graph {
     int device = 0;
-    int64_t N = 0, row_begin = 0, n_rows = 0, E = 0, n_masked = 0;
+    // N: size of the index space adj_src refers to = rows of the state replica / of `nodes` (all nodes, or own rows + halo
+    // slots of a boundary-exchange shard); N_global: nodes of the whole graph; row_begin: GLOBAL id of the first owned row;
+    // own_off: index of the first owned row inside that index space (== row_begin for full replicas, 0 for halo shards)
+    int64_t N = 0, N_global = 0, row_begin = 0, own_off = 0, n_rows = 0, E = 0, n_masked = 0;
     int NL = 0, AL = 0;
+    // boundary ("halo") exchange plan of a shard created by gnn_graph_create_halo, else halo_world == 0
+    int halo_world = 0, halo_rank = 0;
+    int64_t halo_block = 0, halo_count = 0;      // rows per rank block in the replica, boundary rows this rank sends
+    int32_t *halo_send = nullptr;                // device [halo_count]: owned-row indices of the boundary rows, ascending
+    int64_t nodes_rows = 0;                      // rows allocated for `nodes` (>= N; derived graphs are padded for the all-gather)
     gnn_graph_shared *sh = nullptr;
     float *nodes = nullptr;   // [N, NL]
     int base_NL = 0;          // derived graphs: label width of the base graph
@@ -137,9 +145,20 @@ struct gnn_mlp {
     uint64_t version = 0;
 };
 
+// In-process loopback group (gnn_comm_create_loopback): `world` communicators on ONE device that share one stream; the
+// exchange steps become device-to-device copies between the members' buffers.  It exists so that the sharded code path
+// (row_begin > 0, padded replicas, per-rank flag slots, the exchange call sites) runs and is checked on a single GPU.
+struct gnn_loop;
+struct gnn_comm_group {
+    int world = 1, refs = 0;
+    hipStream_t stream = nullptr;
+    std::vector<gnn_loop *> member;     // loop registered by each rank (gnn_loop_create), nullptr when none
+};
+
 struct gnn_comm {
     int rank = 0, world = 1, device = 0;
-    void *nccl = nullptr;       // ncclComm_t
+    void *nccl = nullptr;       // ncclComm_t (RCCL communicators)
+    gnn_comm_group *grp = nullptr;   // loopback communicators
     hipStream_t stream = nullptr;
     double *scratch = nullptr;  // device, for allreduce_max
 };
@@ -151,7 +170,7 @@ struct gnn_loop {
     int device = 0, rank = 0, world = 1;
     int D = 0, Ds = 0, NLc = 0, in_s = 0, wf = 0, T = 0, max_iter = 0;
     float thr = 0.f;
-    int64_t shard_rows = 0, N_pad = 0;
+    int64_t shard_rows = 0, N_pad = 0, own_off = 0;   // rows per rank, rows of the state replica, replica row of the first owned row
     hipStream_t stream = nullptr;
     float *state[2] = {nullptr, nullptr};   // [N_pad, Ds] full replicas, ping-pong
     float *state_init = nullptr;            // [n_rows, Ds] initial state of the owned rows (D > 0)
@@ -167,7 +186,7 @@ struct gnn_loop {
     bool have_state0 = false, ran = false;
     int impl_req = 1, impl_used = 0;
     int32_t *ng_ip = nullptr, *ng_node = nullptr;   // cached NodeGraph^T (graph readout)
-    float *ng_w = nullptr, *ng_out = nullptr;
+    float *ng_w = nullptr, *ng_out = nullptr, *ng_part = nullptr;   // ng_part [world, G, T]: per-rank partial readouts
     std::vector<int32_t> ng_key;
     std::vector<float> ng_w_host;
     // edge-based readout (GNNedgeBased.apply_filters): entry -> CSR row, arc labels in original order, masked arc list
@@ -194,6 +213,8 @@ int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float
 int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base);
 // GNNedgeBased.apply_filters on `state` (training path): feats [n_edge_masked, 2 (Ds + NLc) + AL]
 int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state, float *feats);
+
+int gnn_launch_copy_cols(hipStream_t st, int64_t n_rows, int w, const float *src, int64_t lds_, float *dst, int64_t ldd, const int *gate, int world);
 
 // gnn_train.hip
 void gnn_train_ctx_free(gnn_loop *l);

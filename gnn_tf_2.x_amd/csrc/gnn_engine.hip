@@ -386,15 +386,30 @@ __global__ void k_out1(int64_t n_masked, const int32_t *__restrict__ masked_rows
 }
 
 // graph readout: out_graph[g, t] = sum over the stored (node, w) of graph g, ascending node, fmaf(w, out_nodes[node, t])
+// Sharded: a rank sums the nodes it owns ([row_begin, row_begin + n_rows), out_nodes indexed from row_begin); the partial
+// results are then added in rank order by k_sum_partials (exact when no graph straddles two shards: x + 0 == x).
 __global__ void k_readout(int G, int T, const int32_t *__restrict__ indptr, const int32_t *__restrict__ node,
-                          const float *__restrict__ w, const float *__restrict__ out_nodes, float *__restrict__ out_graph)
+                          const float *__restrict__ w, const float *__restrict__ out_nodes, int64_t row_begin, int64_t n_rows,
+                          float *__restrict__ out_graph)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= G * T) return;
     const int g = t / T, c = t - g * T;
     float acc = 0.0f;
-    for (int e = indptr[g]; e < indptr[g + 1]; ++e) acc = __builtin_fmaf(w[e], out_nodes[(int64_t)node[e] * T + c], acc);
+    for (int e = indptr[g]; e < indptr[g + 1]; ++e) {
+        const int64_t i = (int64_t)node[e] - row_begin;
+        if (i >= 0 && i < n_rows) acc = __builtin_fmaf(w[e], out_nodes[i * T + c], acc);
+    }
     out_graph[t] = acc;
+}
+
+__global__ void k_sum_partials(int count, int world, const float *__restrict__ partial, float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    float acc = partial[t];
+    for (int p = 1; p < world; ++p) acc = acc + partial[(size_t)p * count + t];
+    out[t] = acc;
 }
 
 // LGNN.update_graph: dst[i] = [base[i, :NLb] | state[i] (if get_state) | mask[i] ? out[pos(i)] : 0 (if get_output)]
@@ -524,10 +539,13 @@ static int launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, c
                         const int *gate, int world)
 {
     if (n_rows == 0) return GNN_OK;
-    static bool big_lds = false;                           // two staged tiles are 66 KB of dynamic LDS
-    if (!big_lds) {
+    // two staged tiles are 66 KB of dynamic LDS: the limit is a per-device attribute of the kernel, raised once per device
+    static bool big_lds[64] = {false};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !big_lds[dev]) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_check), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4));
-        big_lds = true;
+        if (dev >= 0 && dev < 64) big_lds[dev] = true;
     }
     hipLaunchKernelGGL(k_check, cdiv(n_rows, 256), 256, sizeof(float) * 256 * 33 * (so ? 2 : 1), st, n_rows, d, s, so, thr, flag_out, gate, world);
     HIPCHK(hipGetLastError());
@@ -594,16 +612,16 @@ static void graph_release_shared(gnn_graph_shared *sh)
     delete sh;
 }
 
-extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_rows, int64_t n_arcs,
-                                const int32_t *indptr, const int32_t *adj_src, const float *adj_w, const float *arc_w,
-                                const float *arc_labels, int dim_arc_label, const float *nodes, int dim_node_label,
-                                const uint8_t *mask, int device, gnn_graph **out)
+static int graph_create_impl(int64_t n_index, int64_t n_global, int64_t row_begin, int64_t own_off, int64_t n_rows, int64_t n_arcs,
+                             const int32_t *indptr, const int32_t *adj_src, const float *adj_w, const float *arc_w,
+                             const float *arc_labels, int dim_arc_label, const float *nodes, int dim_node_label,
+                             const uint8_t *mask, int device, gnn_graph **out)
 {
     ARGCHK(out, "out is NULL");
     *out = nullptr;
-    ARGCHK(n_nodes > 0 && n_nodes < (int64_t)1 << 31, "n_nodes=%lld out of range", (long long)n_nodes);
-    ARGCHK(row_begin >= 0 && n_rows >= 0 && row_begin + n_rows <= n_nodes, "owned rows [%lld,+%lld) outside [0,%lld)",
-           (long long)row_begin, (long long)n_rows, (long long)n_nodes);
+    ARGCHK(n_index > 0 && n_index < (int64_t)1 << 31 && n_global > 0 && n_global < (int64_t)1 << 31, "n_nodes=%lld out of range", (long long)n_global);
+    ARGCHK(row_begin >= 0 && n_rows >= 0 && row_begin + n_rows <= n_global && own_off >= 0 && own_off + n_rows <= n_index,
+           "owned rows [%lld,+%lld) outside [0,%lld)", (long long)row_begin, (long long)n_rows, (long long)n_global);
     ARGCHK(n_arcs >= 0 && n_arcs < (int64_t)1 << 31, "n_arcs=%lld out of range", (long long)n_arcs);
     ARGCHK(dim_node_label > 0 && dim_arc_label >= 0, "label dims must be NL>0, AL>=0");
     ARGCHK(indptr && nodes && mask, "indptr/nodes/mask are required");
@@ -617,12 +635,13 @@ extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_ro
         maxdeg = std::max(maxdeg, d);
     }
     for (int64_t e = 0; e < n_arcs; ++e)
-        ARGCHK(adj_src[e] >= 0 && adj_src[e] < n_nodes, "adj_src[%lld]=%d outside [0,%lld)", (long long)e, adj_src[e], (long long)n_nodes);
+        ARGCHK(adj_src[e] >= 0 && adj_src[e] < n_index, "adj_src[%lld]=%d outside [0,%lld)", (long long)e, adj_src[e], (long long)n_index);
 
     HIPCHK(hipSetDevice(device));
     gnn_graph *g = new gnn_graph();
-    g->device = device; g->N = n_nodes; g->row_begin = row_begin; g->n_rows = n_rows; g->E = n_arcs;
+    g->device = device; g->N = n_index; g->N_global = n_global; g->row_begin = row_begin; g->own_off = own_off; g->n_rows = n_rows; g->E = n_arcs;
     g->NL = dim_node_label; g->AL = dim_arc_label; g->base_NL = dim_node_label; g->base_AL = dim_arc_label;
+    g->nodes_rows = n_index;
     g->sh = new gnn_graph_shared();
     g->sh->max_degree = maxdeg;
     // masked_rows holds [n_masked] owned-row indices with mask set, followed by [n_rows] exclusive positions
@@ -636,7 +655,7 @@ extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_ro
         (rc = dev_upload(&g->sh->adj_w, adj_w, (size_t)n_arcs)) || (rc = dev_upload(&g->sh->arc_w, arc_w, (size_t)n_arcs)) ||
         (rc = dev_upload(&g->sh->arc_labels, arc_labels, (size_t)n_arcs * dim_arc_label)) ||
         (rc = dev_upload(&g->sh->mask, mask, (size_t)n_rows)) || (rc = dev_upload(&g->sh->masked_rows, both.data(), both.size())) ||
-        (rc = dev_upload(&g->nodes, nodes, (size_t)n_nodes * dim_node_label))) {
+        (rc = dev_upload(&g->nodes, nodes, (size_t)n_index * dim_node_label))) {
         gnn_graph_destroy(g);
         return rc;
     }
@@ -644,19 +663,96 @@ extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_ro
     return GNN_OK;
 }
 
+extern "C" int gnn_graph_create(int64_t n_nodes, int64_t row_begin, int64_t n_rows, int64_t n_arcs,
+                                const int32_t *indptr, const int32_t *adj_src, const float *adj_w, const float *arc_w,
+                                const float *arc_labels, int dim_arc_label, const float *nodes, int dim_node_label,
+                                const uint8_t *mask, int device, gnn_graph **out)
+{
+    return graph_create_impl(n_nodes, n_nodes, row_begin, row_begin, n_rows, n_arcs, indptr, adj_src, adj_w, arc_w, arc_labels, dim_arc_label,
+                             nodes, dim_node_label, mask, device, out);
+}
+
+// Shard with a BOUNDARY exchange ("halo"): the state replica of rank r holds its own shard followed by one block per rank
+// with only the rows that some OTHER rank reads (gnn_halo_plan computes the blocks from the whole graph), so the
+// per-iteration all-gather moves boundary rows instead of whole shards.  Index space of adj_src / nodes:
+//   [0, shard)                           owned rows (shard = rows per rank of gnn_shard_range, the last shard may be short)
+//   shard + q * block + j                j-th boundary row of rank q (ascending global id), j < count_q <= block
+extern "C" int gnn_graph_create_halo(int64_t n_nodes_global, int rank, int world, int64_t halo_block, int64_t n_send, const int32_t *send_rows,
+                                     int64_t n_arcs, const int32_t *indptr, const int32_t *adj_src_replica, const float *adj_w,
+                                     const float *arc_w, const float *arc_labels, int dim_arc_label, const float *nodes_replica,
+                                     int dim_node_label, const uint8_t *mask, int device, gnn_graph **out)
+{
+    ARGCHK(out, "out is NULL");
+    *out = nullptr;
+    ARGCHK(world >= 2 && rank >= 0 && rank < world && halo_block >= 0 && n_send >= 0 && n_send <= halo_block && (n_send == 0 || send_rows), "bad halo description");
+    int64_t rb = 0, nr = 0;
+    int rc = gnn_shard_range(n_nodes_global, rank, world, &rb, &nr);
+    if (rc) return rc;
+    const int64_t shard = ((n_nodes_global + world - 1) / world + 31) / 32 * 32;
+    for (int64_t j = 0; j < n_send; ++j)
+        ARGCHK(send_rows[j] >= 0 && send_rows[j] < nr && (j == 0 || send_rows[j] > send_rows[j - 1]), "send_rows must be ascending owned-row indices");
+    const int64_t n_index = shard + (int64_t)world * halo_block;
+    rc = graph_create_impl(n_index, n_nodes_global, rb, 0, nr, n_arcs, indptr, adj_src_replica, adj_w, arc_w, arc_labels, dim_arc_label, nodes_replica,
+                           dim_node_label, mask, device, out);
+    if (rc) return rc;
+    gnn_graph *g = *out;
+    g->halo_world = world; g->halo_rank = rank; g->halo_block = halo_block; g->halo_count = n_send;
+    rc = dev_upload(&g->halo_send, send_rows, (size_t)n_send);
+    if (rc) { gnn_graph_destroy(g); *out = nullptr; return rc; }
+    return GNN_OK;
+}
+
+// Host helper for gnn_graph_create_halo: from the CSR-by-destination of the WHOLE graph, the boundary rows of every rank.
+// is_boundary[v] = 1 iff some arc v -> d has owner(d) != owner(v); counts[q] = boundary rows owned by rank q;
+// slot[v] = position of v among the boundary rows of its owner (ascending id), -1 otherwise.  *block = max_q counts[q].
+extern "C" int gnn_halo_plan(int64_t n_nodes, int world, const int32_t *indptr, const int32_t *adj_src, int32_t *slot, int64_t *counts, int64_t *block)
+{
+    ARGCHK(n_nodes > 0 && world >= 1 && indptr && slot && counts && block, "bad arguments");
+    const int64_t shard = ((n_nodes + world - 1) / world + 31) / 32 * 32;
+    std::vector<uint8_t> bnd((size_t)n_nodes, 0);
+    for (int64_t d = 0; d < n_nodes; ++d) {
+        const int64_t od = d / shard;
+        for (int32_t e = indptr[d]; e < indptr[d + 1]; ++e) {
+            const int32_t v = adj_src[e];
+            ARGCHK(v >= 0 && v < n_nodes, "adj_src[%d]=%d outside [0,%lld)", e, v, (long long)n_nodes);
+            if (v / shard != od) bnd[v] = 1;
+        }
+    }
+    int64_t mx = 0;
+    for (int q = 0; q < world; ++q) {
+        int64_t c = 0;
+        const int64_t b = std::min<int64_t>(n_nodes, shard * q), e = std::min<int64_t>(n_nodes, shard * (q + 1));
+        for (int64_t v = b; v < e; ++v) slot[v] = bnd[v] ? (int32_t)c++ : -1;
+        counts[q] = c;
+        mx = std::max(mx, c);
+    }
+    *block = mx;
+    return GNN_OK;
+}
+
 static inline const int32_t *graph_mask_pos(const gnn_graph *g) { return g->sh->masked_rows + g->n_masked; }
+
+// rows allocated for the node labels of a derived graph: the sharded relabelling all-gathers whole shards in place, and
+// shard * world <= N + 33 * world
+static inline int64_t derived_node_rows(int64_t n) { return n + 33 * 64; }
 
 extern "C" int gnn_graph_derive(const gnn_graph *base, int extra, gnn_graph **out)
 {
     ARGCHK(base && out && extra >= 0, "bad arguments");
+    *out = nullptr;
+    ARGCHK(!base->halo_world, "LGNN relabelling is not available on boundary-exchange shards (use full-replica shards)");
     HIPCHK(hipSetDevice(base->device));
     gnn_graph *g = new gnn_graph(*base);
     g->sh->refs++;
     g->NL = base->base_NL + extra;
     g->nodes = nullptr;
-    int rc = dev_alloc(&g->nodes, (size_t)g->N * g->NL);
+    g->arc_labels_own = g->arc_labels_orig_own = nullptr;      // never share the owned arc labels of a derived base
+    g->halo_send = nullptr;
+    g->AL = base->base_AL;
+    g->nodes_rows = derived_node_rows(g->N);
+    int rc = dev_alloc(&g->nodes, (size_t)g->nodes_rows * g->NL);
+    if (!rc && hipMemset(g->nodes, 0, (size_t)g->nodes_rows * g->NL * sizeof(float)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipMemset of the derived node labels failed");
     if (rc) { gnn_graph_destroy(g); return rc; }
-    HIPCHK(hipMemset(g->nodes, 0, (size_t)g->N * g->NL * sizeof(float)));
     *out = g;
     return GNN_OK;
 }
@@ -682,6 +778,7 @@ extern "C" int gnn_graph_derive_edge(const gnn_graph *base, int extra_nodes, int
 {
     ARGCHK(base && out && extra_nodes >= 0 && extra_arcs >= 0, "bad arguments");
     ARGCHK(base->sh->arc_id, "call gnn_graph_set_arc_order on the base graph first");
+    ARGCHK(base->n_rows == base->N, "edge-based LGNN stacks are single-GPU only");
     int rc = gnn_graph_derive(base, extra_nodes, out);
     if (rc) return rc;
     gnn_graph *g = *out;
@@ -690,9 +787,10 @@ extern "C" int gnn_graph_derive_edge(const gnn_graph *base, int extra_nodes, int
     g->arc_labels_own = g->arc_labels_orig_own = nullptr;
     rc = dev_alloc(&g->arc_labels_own, (size_t)g->E * g->AL);
     if (!rc) rc = dev_alloc(&g->arc_labels_orig_own, (size_t)g->E * g->AL);
+    if (!rc && (hipMemset(g->arc_labels_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)) != hipSuccess ||
+                hipMemset(g->arc_labels_orig_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)) != hipSuccess))
+        rc = gnn_fail(GNN_ERR_HIP, "hipMemset of the derived arc labels failed");
     if (rc) { gnn_graph_destroy(g); return rc; }
-    HIPCHK(hipMemset(g->arc_labels_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)));
-    HIPCHK(hipMemset(g->arc_labels_orig_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)));
     *out = g;
     return GNN_OK;
 }
@@ -701,7 +799,7 @@ extern "C" int gnn_graph_get_nodes(const gnn_graph *g, float *nodes_out)
 {
     ARGCHK(g && nodes_out, "bad arguments");
     HIPCHK(hipSetDevice(g->device));
-    HIPCHK(hipMemcpy(nodes_out, g->nodes, (size_t)g->N * g->NL * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nodes_out, g->nodes, (size_t)g->N * g->NL * sizeof(float), hipMemcpyDeviceToHost));   // index-space rows (all nodes for full replicas)
     return GNN_OK;
 }
 
@@ -720,9 +818,9 @@ extern "C" int gnn_graph_dims(const gnn_graph *g, int64_t *n_nodes, int64_t *n_r
 
 extern "C" int gnn_graph_destroy(gnn_graph *g)
 {
-    if (g) { (void)hipFree(g->arc_labels_own); (void)hipFree(g->arc_labels_orig_own); }
     if (!g) return GNN_OK;
     (void)hipSetDevice(g->device);
+    (void)hipFree(g->arc_labels_own); (void)hipFree(g->arc_labels_orig_own); (void)hipFree(g->halo_send);
     (void)hipFree(g->nodes);
     graph_release_shared(g->sh);
     delete g;
@@ -893,9 +991,31 @@ extern "C" int gnn_comm_create(const uint8_t id[128], int rank, int world, int d
     memcpy(uid.b, id, 128);
     int r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
     if (r != 0) { delete c; return gnn_fail(GNN_ERR_COMM, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r)); }
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&c->scratch, sizeof(double)));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&c->scratch, sizeof(double)) != hipSuccess) {
+        gnn_comm_destroy(c);
+        return gnn_fail(GNN_ERR_HIP, "communicator stream / scratch allocation failed");
+    }
     *out = c;
+    return GNN_OK;
+}
+
+// `world` communicators on ONE device sharing one stream (see gnn_comm_group): the sharded engine path on a single GPU.
+extern "C" int gnn_comm_create_loopback(int world, int device, gnn_comm **out /* [world] */)
+{
+    ARGCHK(out && world >= 1 && world <= 64, "bad arguments");
+    for (int r = 0; r < world; ++r) out[r] = nullptr;
+    HIPCHK(hipSetDevice(device));
+    gnn_comm_group *grp = new gnn_comm_group();
+    grp->world = world;
+    grp->member.assign((size_t)world, nullptr);
+    hipError_t e = hipStreamCreateWithFlags(&grp->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete grp; return gnn_fail(GNN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    for (int r = 0; r < world; ++r) {
+        gnn_comm *c = new gnn_comm();
+        c->rank = r; c->world = world; c->device = device; c->grp = grp; c->stream = grp->stream;
+        grp->refs++;
+        out[r] = c;
+    }
     return GNN_OK;
 }
 
@@ -903,6 +1023,7 @@ extern "C" int gnn_comm_allreduce_max(gnn_comm *c, double *value)
 {
     ARGCHK(c && value, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
+    if (c->grp) { HIPCHK(hipStreamSynchronize(c->stream)); return GNN_OK; }   // one process: the value is already the maximum
     HIPCHK(hipMemcpyAsync(c->scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
     NCCLCHK(g_rccl.AllReduce(c->scratch, c->scratch, 1, NCCL_FLOAT64, NCCL_MAX, c->nccl, c->stream));
     HIPCHK(hipMemcpyAsync(value, c->scratch, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -914,6 +1035,11 @@ extern "C" int gnn_comm_destroy(gnn_comm *c)
 {
     if (!c) return GNN_OK;
     (void)hipSetDevice(c->device);
+    if (c->grp) {
+        if (--c->grp->refs == 0) { (void)hipStreamDestroy(c->grp->stream); delete c->grp; }
+        delete c;
+        return GNN_OK;
+    }
     if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipFree(c->scratch);
@@ -952,8 +1078,11 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     ARGCHK(net_output->dims[0] == Ds + NLc || edge_width, "net_output input width %d is neither NL + D = %d (node/graph based) nor 2 (NL + D) + AL = %d (edge based)",
            net_output->dims[0], Ds + NLc, 2 * (Ds + NLc) + g->AL);
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    ARGCHK(!g->halo_world || (g->halo_world == world && g->halo_rank == rank), "boundary-exchange shard of rank %d/%d used with rank %d/%d",
+           g->halo_rank, g->halo_world, rank, world);
+    ARGCHK(!comm || !comm->grp || !comm->grp->member[rank], "loopback rank %d already has a loop (one loop per rank and group)", rank);
     int64_t rb = 0, nr = 0;
-    gnn_shard_range(g->N, rank, world, &rb, &nr);
+    gnn_shard_range(g->N_global, rank, world, &rb, &nr);
     ARGCHK(rb == g->row_begin && nr == g->n_rows, "graph owns rows [%lld,+%lld) but rank %d/%d must own [%lld,+%lld)",
            (long long)g->row_begin, (long long)g->n_rows, rank, world, (long long)rb, (long long)nr);
     ARGCHK(!comm || comm->device == g->device, "communicator and graph live on different devices");
@@ -964,8 +1093,9 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     l->D = state_dim; l->Ds = Ds; l->NLc = NLc; l->in_s = in_s; l->wf = Ds + NLc; l->T = net_output->dims.back();
     l->max_iter = max_iter; l->thr = threshold;
     l->edge_expected = edge_width;
-    l->shard_rows = ((g->N + world - 1) / world + 31) / 32 * 32;
-    l->N_pad = l->shard_rows * world;
+    l->shard_rows = ((g->N_global + world - 1) / world + 31) / 32 * 32;
+    l->N_pad = g->halo_world ? g->N : l->shard_rows * world;                  // rows of the state replica
+    l->own_off = g->halo_world ? 0 : l->shard_rows * rank;
     int rc = 0;
     if (comm) l->stream = comm->stream;
     else {
@@ -994,6 +1124,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     if (rc) { gnn_loop_destroy(l); return rc; }
     l->impl_req = 2;            // fastest supported path by default; gnn_loop_set_impl(1) selects the bit-exact f32 MFMA
     (void)maxw_s;
+    if (comm && comm->grp) comm->grp->member[rank] = l;
     *out = l;
     return GNN_OK;
 }
@@ -1057,14 +1188,90 @@ extern "C" int gnn_loop_set_state0(gnn_loop *l, const float *state0, uint64_t se
     return GNN_OK;
 }
 
-static int loop_allgather(gnn_loop *l, float *state_buf, int *flag_row)
+// ---------------------------------------------------------------------------------------------------------------------
+// exchange step of the sharded loop (reference: the reads of `state` at GNN/GNN.py:234 and the global reduce_any at :218
+// span all nodes; here every rank owns a node range).  One call = "everybody gets the owned state rows of buffer `b` and the
+// flag words at int offset `flag_off` of every rank".  b < 0 / flag_off == NO_FLAGS skip that part.
+//   RCCL communicator      one grouped call: in-place all-gather of the owned rows (full replicas) or of the packed
+//                          boundary rows (halo shards) + all-gather of the rank's flag block
+//   loopback communicator  the same data movement as device-to-device copies into the other members' buffers, on the
+//                          group's single stream (so ordering is program order)
+// ---------------------------------------------------------------------------------------------------------------------
+static const size_t NO_FLAGS = ~(size_t)0;
+
+__global__ void k_pack_rows(int64_t count, int Ds, const int32_t *__restrict__ rows, const float *__restrict__ own, float *__restrict__ dst)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * Ds) return;
+    const int64_t r = t / Ds;
+    const int c = (int)(t - r * Ds);
+    dst[t] = own[(int64_t)rows[r] * Ds + c];
+}
+
+// replica segment this rank publishes: [seg_off, seg_off + seg_rows) rows of the state replica
+static inline void loop_segment(const gnn_loop *l, int rank, size_t *off_rows, size_t *rows)
+{
+    const gnn_graph *g = l->g;
+    if (g->halo_world) { *off_rows = (size_t)l->shard_rows + (size_t)rank * g->halo_block; *rows = (size_t)g->halo_block; }
+    else { *off_rows = (size_t)l->shard_rows * rank; *rows = (size_t)l->shard_rows; }
+}
+
+static int loop_exchange(gnn_loop *l, int b, size_t flag_off)
 {
     if (l->world == 1) return GNN_OK;
-    const size_t cnt = (size_t)l->shard_rows * l->Ds;
+    const gnn_graph *g = l->g;
+    size_t off = 0, rows = 0;
+    loop_segment(l, l->rank, &off, &rows);
+    if (b >= 0 && g->halo_world && g->halo_count) {      // boundary rows of the owned range -> this rank's block of the replica
+        const int64_t tot = g->halo_count * l->Ds;
+        hipLaunchKernelGGL(k_pack_rows, cdiv(tot, 256), 256, 0, l->stream, g->halo_count, l->Ds, g->halo_send, l->state[b] + (size_t)l->own_off * l->Ds,
+                           l->state[b] + off * l->Ds);
+        HIPCHK(hipGetLastError());
+    }
+    if (l->comm->grp) {
+        gnn_comm_group *grp = l->comm->grp;
+        for (int p = 0; p < l->world; ++p) {
+            gnn_loop *peer = grp->member[p];
+            if (p == l->rank) continue;
+            if (!peer) return gnn_fail(GNN_ERR_STATE, "loopback rank %d has no loop: create one loop per rank and run them with gnn_loop_run_group", p);
+            if (b >= 0 && rows)
+                HIPCHK(hipMemcpyAsync(peer->state[b] + off * l->Ds, l->state[b] + off * l->Ds, sizeof(float) * rows * l->Ds, hipMemcpyDeviceToDevice, l->stream));
+            if (flag_off != NO_FLAGS)
+                HIPCHK(hipMemcpyAsync(peer->flags + flag_off + (size_t)l->rank * GNN_FLAG_WORDS, l->flags + flag_off + (size_t)l->rank * GNN_FLAG_WORDS,
+                                      sizeof(int) * GNN_FLAG_WORDS, hipMemcpyDeviceToDevice, l->stream));
+        }
+        return GNN_OK;
+    }
+    size_t base = 0, unused = 0;
+    loop_segment(l, 0, &base, &unused);
     NCCLCHK(g_rccl.GroupStart());
-    if (state_buf) NCCLCHK(g_rccl.AllGather(state_buf + cnt * l->rank, state_buf, cnt, NCCL_FLOAT32, l->comm->nccl, l->stream));
-    if (flag_row) NCCLCHK(g_rccl.AllGather(flag_row + (size_t)l->rank * GNN_FLAG_WORDS, flag_row, GNN_FLAG_WORDS, NCCL_INT32, l->comm->nccl, l->stream));
+    if (b >= 0 && rows)
+        NCCLCHK(g_rccl.AllGather(l->state[b] + off * l->Ds, l->state[b] + base * l->Ds, rows * l->Ds, NCCL_FLOAT32, l->comm->nccl, l->stream));
+    if (flag_off != NO_FLAGS)
+        NCCLCHK(g_rccl.AllGather(l->flags + flag_off + (size_t)l->rank * GNN_FLAG_WORDS, l->flags + flag_off, GNN_FLAG_WORDS, NCCL_INT32, l->comm->nccl, l->stream));
     NCCLCHK(g_rccl.GroupEnd());
+    return GNN_OK;
+}
+
+// dst[r, 0:w) = src[r, 0:w) for r < n_rows (strided rows on both sides).  Own kernel instead of hipMemcpy2DAsync: the
+// runtime's 2-D device-to-device copy was the only HIP call of the per-op path that the fused path never makes, and a
+// profiled run (rocprofv3 --kernel-trace) of the per-op path died inside the runtime on its first use.
+__global__ void k_copy_cols(int64_t n_rows, int w, const float *__restrict__ src, int64_t lds_, float *__restrict__ dst, int64_t ldd,
+                            const int *gate, int world)
+{
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * w) return;
+    const int64_t r = t / w;
+    const int c = (int)(t - r * w);
+    dst[r * ldd + c] = src[r * lds_ + c];
+}
+
+int gnn_launch_copy_cols(hipStream_t st, int64_t n_rows, int w, const float *src, int64_t lds_, float *dst, int64_t ldd, const int *gate, int world)
+{
+    if (n_rows == 0 || w == 0) return GNN_OK;
+    hipLaunchKernelGGL(k_copy_cols, cdiv(n_rows * w, 256), 256, 0, st, n_rows, w, src, lds_, dst, ldd, gate, world);
+    HIPCHK(hipGetLastError());
     return GNN_OK;
 }
 
@@ -1073,14 +1280,13 @@ static int unfused_iteration(gnn_loop *l, int k)
     const gnn_graph *g = l->g;
     const int cur = k & 1, nxt = cur ^ 1, P = l->world;
     const int *gate = l->flags + (size_t)k * P * GNN_FLAG_WORDS;
-    const float *own_cur = l->state[cur] + (size_t)g->row_begin * l->Ds;
-    float *own_nxt = l->state[nxt] + (size_t)g->row_begin * l->Ds;
+    const float *own_cur = l->state[cur] + (size_t)l->own_off * l->Ds;
+    float *own_nxt = l->state[nxt] + (size_t)l->own_off * l->Ds;
     // node_components (GNN.py:228): own state into columns [0, Ds) of the concat
-    if (g->n_rows)
-        HIPCHK(hipMemcpy2DAsync(l->inp, sizeof(float) * l->in_s, own_cur, sizeof(float) * l->Ds, sizeof(float) * l->Ds,
-                                (size_t)g->n_rows, hipMemcpyDeviceToDevice, l->stream));
+    int rc = gnn_launch_copy_cols(l->stream, g->n_rows, l->Ds, own_cur, l->Ds, l->inp, l->in_s, gate, P);
+    if (rc) return rc;
     // aggregated_states (GNN.py:234) into columns [Ds + NLc, +Ds)
-    int rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
+    rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
                          l->inp + l->Ds + l->NLc, l->in_s, gate, P);
     if (rc) return rc;
     // net_state (GNN.py:240)
@@ -1090,10 +1296,11 @@ static int unfused_iteration(gnn_loop *l, int k)
     return launch_check(l->stream, g->n_rows, l->Ds, own_nxt, own_cur, l->thr, l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS, gate, P);
 }
 
-// Everything one Loop puts on the stream between the first condition and net_output.  Bodies are enqueued without waiting
-// for each other; every GNN_BODY_CHUNK bodies the gate of the next body is copied to the host and checked, so that a loop
-// that converged does not pay for max_iteration - k empty launches (about 3 us each).
-static int loop_enqueue(gnn_loop *l, bool fused)
+// ---- phases of one Loop; gnn_loop_run runs them for one rank, gnn_loop_run_group rank by rank for a loopback group ----------
+static inline bool loop_is_fused(gnn_loop *l) { return l->impl_req >= 1 && gnn_fused_supported(l); }
+
+// state <- initial state, first condition against ones (GNN.py:262-271), loop-invariant aggregates (GNN.py:259, :263)
+static int loop_begin(gnn_loop *l, bool fused)
 {
     gnn_graph *g = l->g;
     const int P = l->world;
@@ -1101,15 +1308,12 @@ static int loop_enqueue(gnn_loop *l, bool fused)
     int rc = 0;
     HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P * GNN_FLAG_WORDS, st));
     HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * (((size_t)l->max_iter + 1 + 3) & ~(size_t)3), st));
-    float *own0 = l->state[0] + (size_t)g->row_begin * l->Ds;
+    float *own0 = l->state[0] + (size_t)l->own_off * l->Ds;
     if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
-        HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->row_begin * g->NL,
+        HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->own_off * g->NL,
                               sizeof(float) * (size_t)g->n_rows * l->Ds, hipMemcpyDeviceToDevice, st));
     // first condition: state vs ones (GNN.py:266, :271)
     if ((rc = launch_check(st, g->n_rows, l->Ds, own0, nullptr, l->thr, l->flags + (size_t)l->rank * GNN_FLAG_WORDS, nullptr, 1))) return rc;
-    if ((rc = loop_allgather(l, l->state[0], l->flags))) return rc;
-
-    // loop-invariant aggregates (GNN.py:259, :263)
     if (!fused) {
         const int c_nodes = l->Ds, c_aggn = l->Ds + l->NLc + l->Ds, c_agga = c_aggn + l->NLc;
         rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, l->inp + c_agga, l->in_s, nullptr, 1);
@@ -1117,31 +1321,45 @@ static int loop_enqueue(gnn_loop *l, bool fused)
         if (l->D) {
             rc = gnn_launch_spmm(st, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, l->inp + c_aggn, l->in_s, nullptr, 1);
             if (rc) return rc;
-            if (g->n_rows)
-                HIPCHK(hipMemcpy2DAsync(l->inp + c_nodes, sizeof(float) * l->in_s, g->nodes + (size_t)g->row_begin * g->NL, sizeof(float) * g->NL,
-                                        sizeof(float) * g->NL, (size_t)g->n_rows, hipMemcpyDeviceToDevice, st));
+            rc = gnn_launch_copy_cols(st, g->n_rows, g->NL, g->nodes + (size_t)g->own_off * g->NL, g->NL, l->inp + c_nodes, l->in_s, nullptr, 1);
+            if (rc) return rc;
         }
     }
+    return GNN_OK;
+}
 
-    for (int k = 0; k < l->max_iter; ++k) {
-        if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k], st));
-        rc = fused ? gnn_fused_iteration(l, k) : unfused_iteration(l, k);
-        if (rc) return rc;
-        if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k + 1], st));
-        if ((rc = loop_allgather(l, l->state[(k & 1) ^ 1], l->flags + (size_t)(k + 1) * P * GNN_FLAG_WORDS))) return rc;
-        if ((k + 1) % GNN_BODY_CHUNK == 0 && k + 1 < l->max_iter) {
-            // every rank reads the same all-gathered gate, so all ranks stop at the same body
-            const size_t words = (size_t)P * GNN_FLAG_WORDS;
-            HIPCHK(hipMemcpyAsync(l->gate_host, l->flags + (size_t)(k + 1) * words, sizeof(int) * words, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            int any = 0;
-            for (size_t i = 0; i < words; i += GNN_FLAG_STRIDE) any |= l->gate_host[i];
-            if (!any) break;
-        }
-    }
-    hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, P, l->max_iter, l->kfinal_dev);
+static int loop_body(gnn_loop *l, int k, bool fused)
+{
+    if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k], l->stream));
+    int rc = fused ? gnn_fused_iteration(l, k) : unfused_iteration(l, k);
+    if (rc) return rc;
+    if (l->profiling) HIPCHK(hipEventRecord(l->ev[2 * k + 1], l->stream));
+    return GNN_OK;
+}
+
+// gate of body k -> host; every rank reads the same exchanged gate, so all ranks stop at the same body
+static int loop_gate_closed(gnn_loop *l, int k, bool *closed)
+{
+    const size_t words = (size_t)l->world * GNN_FLAG_WORDS;
+    HIPCHK(hipMemcpyAsync(l->gate_host, l->flags + (size_t)k * words, sizeof(int) * words, hipMemcpyDeviceToHost, l->stream));
+    HIPCHK(hipStreamSynchronize(l->stream));
+    int any = 0;
+    for (size_t i = 0; i < words; i += GNN_FLAG_STRIDE) any |= l->gate_host[i];
+    *closed = !any;
+    return GNN_OK;
+}
+
+// k, apply_filters + net_output on the owned masked rows (GNN.py:275-279)
+static int loop_finish(gnn_loop *l)
+{
+    gnn_graph *g = l->g;
+    hipStream_t st = l->stream;
+    int rc = 0;
+    hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, l->world, l->max_iter, l->kfinal_dev);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    const float *own0 = l->state[0] + (size_t)l->own_off * l->Ds, *own1 = l->state[1] + (size_t)l->own_off * l->Ds;
+    const float *nodes_own = g->nodes + (size_t)g->own_off * g->NL;
 
     if (l->edge_mode) {      // GNNedgeBased.apply_filters + net_output on the masked arcs (GNN.py:289-302, :279)
         if (l->n_edge_masked) {
@@ -1155,19 +1373,16 @@ static int loop_enqueue(gnn_loop *l, bool fused)
         }
         return GNN_OK;
     }
-    // apply_filters + net_output on the owned masked rows (GNN.py:275-279)
     const size_t out1_lds = sizeof(float) * ((size_t)(l->wf + 1) * l->T + (size_t)GNN_OUT1_ROWS * (l->wf | 1) + (size_t)GNN_OUT1_ROWS * l->T);
     if (g->n_masked && l->ou->n_layers == 1 && l->T <= 8 && out1_lds <= 64 * 1024) {
         const gnn_mlp *ou = l->ou;
         hipLaunchKernelGGL(k_out1, cdiv(g->n_masked, GNN_OUT1_ROWS), GNN_OUT1_ROWS * l->T < 64 ? 64 : GNN_OUT1_ROWS * l->T, out1_lds, st, g->n_masked, g->sh->masked_rows,
-                           l->state[0] + (size_t)g->row_begin * l->Ds, l->state[1] + (size_t)g->row_begin * l->Ds, l->kfinal_dev, l->Ds,
-                           g->nodes + (size_t)g->row_begin * g->NL, g->NL, l->NLc, ou->W[0], ou->b[0], l->T, ou->acts[0],
+                           own0, own1, l->kfinal_dev, l->Ds, nodes_own, g->NL, l->NLc, ou->W[0], ou->b[0], l->T, ou->acts[0],
                            ou->has_bn ? ou->bn_scale : (const float *)nullptr, ou->has_bn ? ou->bn_shift : (const float *)nullptr, l->out);
         HIPCHK(hipGetLastError());
     } else if (g->n_masked) {
         const int64_t tot = g->n_masked * l->wf;
-        hipLaunchKernelGGL(k_feats, cdiv(tot, 256), 256, 0, st, g->n_masked, g->sh->masked_rows, l->state[0] + (size_t)g->row_begin * l->Ds,
-                           l->state[1] + (size_t)g->row_begin * l->Ds, l->kfinal_dev, l->Ds, g->nodes + (size_t)g->row_begin * g->NL, g->NL, l->NLc, l->feats);
+        hipLaunchKernelGGL(k_feats, cdiv(tot, 256), 256, 0, st, g->n_masked, g->sh->masked_rows, own0, own1, l->kfinal_dev, l->Ds, nodes_own, g->NL, l->NLc, l->feats);
         HIPCHK(hipGetLastError());
         rc = launch_mlp(st, l->ou, g->n_masked, l->feats, l->wf, l->out, l->T, l->otmp[0], l->otmp[1], nullptr, 1);
         if (rc) return rc;
@@ -1175,10 +1390,8 @@ static int loop_enqueue(gnn_loop *l, bool fused)
     return GNN_OK;
 }
 
-extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
+static int loop_prepare(gnn_loop *l, bool *fused_out)
 {
-    ARGCHK(l, "loop is NULL");
-    if (training) return gnn_fail(GNN_ERR_UNSUPPORTED, "training=True (backward through the loop) is not implemented on the device yet");
     if (!l->have_state0) {
         if (l->D == 0) l->have_state0 = true;
         else return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
@@ -1186,21 +1399,21 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     if (l->edge_expected && !l->edge_mode)
         return gnn_fail(GNN_ERR_STATE, "net_output has the edge-based input width: call gnn_loop_set_edge_readout first");
     HIPCHK(hipSetDevice(l->device));
-    hipStream_t st = l->stream;
-    const bool fused = l->impl_req >= 1 && gnn_fused_supported(l);
+    const bool fused = loop_is_fused(l);
     l->impl_used = fused ? l->impl_req : 0;
     int rc = fused ? gnn_fused_prepare(l) : loop_ensure_unfused(l);
     if (rc) return rc;
     if (l->profiling && (int)l->ev.size() < 2 * l->max_iter) {
         const size_t old = l->ev.size();
-        l->ev.resize(2 * (size_t)l->max_iter);
+        l->ev.resize(2 * (size_t)l->max_iter, nullptr);
         for (size_t i = old; i < l->ev.size(); ++i) HIPCHK(hipEventCreate(&l->ev[i]));
     }
+    *fused_out = fused;
+    return GNN_OK;
+}
 
-    HIPCHK(hipEventRecord(l->ev_total[0], st));
-    if ((rc = loop_enqueue(l, fused))) return rc;
-    HIPCHK(hipEventRecord(l->ev_total[1], st));
-    HIPCHK(hipStreamSynchronize(st));
+static int loop_collect(gnn_loop *l, float *k_out)
+{
     l->kfinal = *l->kfinal_host;
     l->ran = true;
     HIPCHK(hipEventElapsedTime(&l->total_ms, l->ev_total[0], l->ev_total[1]));
@@ -1220,12 +1433,79 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     return GNN_OK;
 }
 
+// Everything the ranks in `ls` put on their streams for one Loop.  Bodies are enqueued without waiting for each other;
+// every GNN_BODY_CHUNK bodies the gate of the next body is copied to the host and checked, so that a loop that converged
+// does not pay for max_iteration - k empty launches (about 3 us each).  n == 1: one rank of an RCCL job (or a single GPU);
+// n == world: all ranks of a loopback group, stepped phase by phase on the group's stream.
+static int run_loops(gnn_loop **ls, int n, float *k_out)
+{
+    std::vector<char> fused((size_t)n, 0);
+    int rc = 0;
+    for (int r = 0; r < n; ++r) {
+        bool f = false;
+        if ((rc = loop_prepare(ls[r], &f))) return rc;
+        fused[r] = f;
+    }
+    const int max_iter = ls[0]->max_iter;
+    for (int r = 0; r < n; ++r) {
+        HIPCHK(hipEventRecord(ls[r]->ev_total[0], ls[r]->stream));
+        if ((rc = loop_begin(ls[r], fused[r]))) return rc;
+    }
+    for (int r = 0; r < n; ++r) if ((rc = loop_exchange(ls[r], 0, 0))) return rc;
+    for (int k = 0; k < max_iter; ++k) {
+        for (int r = 0; r < n; ++r) if ((rc = loop_body(ls[r], k, fused[r]))) return rc;
+        for (int r = 0; r < n; ++r)
+            if ((rc = loop_exchange(ls[r], (k & 1) ^ 1, (size_t)(k + 1) * ls[r]->world * GNN_FLAG_WORDS))) return rc;
+        if ((k + 1) % GNN_BODY_CHUNK == 0 && k + 1 < max_iter) {
+            bool closed = false, c = false;
+            for (int r = 0; r < n; ++r) {
+                if ((rc = loop_gate_closed(ls[r], k + 1, &c))) return rc;
+                if (r == 0) closed = c;
+                else if (c != closed) return gnn_fail(GNN_ERR_STATE, "ranks disagree on the gate of body %d", k + 1);
+            }
+            if (closed) break;
+        }
+    }
+    for (int r = 0; r < n; ++r) {
+        if ((rc = loop_finish(ls[r]))) return rc;
+        HIPCHK(hipEventRecord(ls[r]->ev_total[1], ls[r]->stream));
+    }
+    for (int r = 0; r < n; ++r) HIPCHK(hipStreamSynchronize(ls[r]->stream));
+    for (int r = 0; r < n; ++r) {
+        float k = 0.f;
+        if ((rc = loop_collect(ls[r], &k))) return rc;
+        if (r && ls[r]->kfinal != ls[0]->kfinal) return gnn_fail(GNN_ERR_STATE, "ranks disagree on the iteration count (%d vs %d)", ls[r]->kfinal, ls[0]->kfinal);
+        if (r == 0 && k_out) *k_out = k;
+    }
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
+{
+    ARGCHK(l, "loop is NULL");
+    if (training) return gnn_fail(GNN_ERR_UNSUPPORTED, "gnn_loop_run is the inference Loop; the training-mode Loop is gnn_loop_train_forward / gnn_loop_train_step");
+    if (l->comm && l->comm->grp && l->world > 1)
+        return gnn_fail(GNN_ERR_STATE, "this loop belongs to a loopback group of %d ranks: run all of them with gnn_loop_run_group", l->world);
+    return run_loops(&l, 1, k_out);
+}
+
+extern "C" int gnn_loop_run_group(gnn_loop **loops, int n, float *k_out)
+{
+    ARGCHK(loops && n >= 1, "bad arguments");
+    for (int r = 0; r < n; ++r) {
+        ARGCHK(loops[r] && loops[r]->comm && loops[r]->comm->grp, "loops[%d] was not created on a loopback communicator", r);
+        ARGCHK(loops[r]->comm->grp == loops[0]->comm->grp && loops[r]->world == n && loops[r]->rank == r, "loops must be the %d ranks of one loopback group, in rank order", n);
+        ARGCHK(loops[r]->max_iter == loops[0]->max_iter && loops[r]->thr == loops[0]->thr && loops[r]->Ds == loops[0]->Ds, "ranks were configured differently");
+    }
+    return run_loops(loops, n, k_out);
+}
+
 extern "C" int gnn_loop_get_state(const gnn_loop *l, float *state_out)
 {
     ARGCHK(l && state_out, "bad arguments");
     if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
     HIPCHK(hipSetDevice(l->device));
-    const float *src = l->state[l->kfinal & 1] + (size_t)l->g->row_begin * l->Ds;
+    const float *src = l->state[l->kfinal & 1] + (size_t)l->own_off * l->Ds;
     HIPCHK(hipMemcpy(state_out, src, sizeof(float) * (size_t)l->g->n_rows * l->Ds, hipMemcpyDeviceToHost));
     return GNN_OK;
 }
@@ -1274,61 +1554,115 @@ extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, 
     return GNN_OK;
 }
 
-extern "C" int gnn_loop_readout(const gnn_loop *l, int G, const int32_t *ng_indptr, const int32_t *ng_node,
-                                const float *ng_w, float *out_graph)
+// NodeGraph^T on the device (kept with the loop, re-uploaded only when it changes) + the partial readout of the owned rows
+static int readout_partial(gnn_loop *lm, int G, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w)
 {
-    ARGCHK(l && G > 0 && ng_indptr && out_graph, "bad arguments");
-    if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    ARGCHK(lm && G > 0 && ng_indptr, "bad arguments");
+    if (!lm->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    ARGCHK(!lm->edge_mode, "graph readout of an edge-based loop");
+    const gnn_graph *g = lm->g;
+    ARGCHK(g->n_masked == g->n_rows, "graph-based readout needs all-true masks (GNN.py:275-276, :332): %lld of %lld owned rows are masked in",
+           (long long)g->n_masked, (long long)g->n_rows);
     const int nnz = ng_indptr[G];
     ARGCHK(ng_indptr[0] == 0 && nnz >= 0 && (nnz == 0 || (ng_node && ng_w)), "bad NodeGraph CSR");
     for (int e = 0; e < nnz; ++e)
-        ARGCHK(ng_node[e] >= 0 && ng_node[e] < l->g->n_masked, "NodeGraph row %d but only %lld output rows (masks must be all-true for graph-based problems)",
-               ng_node[e], (long long)l->g->n_masked);
-    HIPCHK(hipSetDevice(l->device));
-    // NodeGraph^T rarely changes between calls on the same loop: keep it on the device and re-upload only when it differs
-    gnn_loop *lm = const_cast<gnn_loop *>(l);
+        ARGCHK(ng_node[e] >= 0 && ng_node[e] < g->N_global, "NodeGraph row %d but the graph has %lld nodes", ng_node[e], (long long)g->N_global);
+    HIPCHK(hipSetDevice(lm->device));
     std::vector<int32_t> key(ng_indptr, ng_indptr + G + 1);
     key.insert(key.end(), ng_node, ng_node + nnz);
     const bool same = lm->ng_key == key && lm->ng_w_host.size() == (size_t)nnz &&
                       (nnz == 0 || memcmp(lm->ng_w_host.data(), ng_w, sizeof(float) * nnz) == 0);
     int rc = GNN_OK;
     if (!same) {
-        (void)hipFree(lm->ng_ip); (void)hipFree(lm->ng_node); (void)hipFree(lm->ng_w); (void)hipFree(lm->ng_out);
-        lm->ng_ip = lm->ng_node = nullptr; lm->ng_w = lm->ng_out = nullptr;
+        (void)hipFree(lm->ng_ip); (void)hipFree(lm->ng_node); (void)hipFree(lm->ng_w); (void)hipFree(lm->ng_out); (void)hipFree(lm->ng_part);
+        lm->ng_ip = lm->ng_node = nullptr; lm->ng_w = lm->ng_out = lm->ng_part = nullptr;
         lm->ng_key.clear();
         rc = dev_upload(&lm->ng_ip, ng_indptr, (size_t)G + 1);
         if (!rc) rc = dev_upload(&lm->ng_node, ng_node, (size_t)nnz);
         if (!rc) rc = dev_upload(&lm->ng_w, ng_w, (size_t)nnz);
-        if (!rc) rc = dev_alloc(&lm->ng_out, (size_t)G * l->T);
+        if (!rc) rc = dev_alloc(&lm->ng_out, (size_t)G * lm->T);
+        if (!rc && lm->world > 1) rc = dev_alloc(&lm->ng_part, (size_t)lm->world * G * lm->T);
         if (rc) return rc;
         lm->ng_key = key;
         lm->ng_w_host.assign(ng_w, ng_w + nnz);
     }
-    hipLaunchKernelGGL(k_readout, cdiv((int64_t)G * l->T, 64), 64, 0, l->stream, G, l->T, lm->ng_ip, lm->ng_node, lm->ng_w, l->out, lm->ng_out);
+    float *dst = lm->world > 1 ? lm->ng_part + (size_t)lm->rank * G * lm->T : lm->ng_out;
+    hipLaunchKernelGGL(k_readout, cdiv((int64_t)G * lm->T, 64), 64, 0, lm->stream, G, lm->T, lm->ng_ip, lm->ng_node, lm->ng_w, lm->out, g->row_begin, g->n_rows, dst);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_graph, lm->ng_out, sizeof(float) * (size_t)G * l->T, hipMemcpyDeviceToHost, l->stream));
-    HIPCHK(hipStreamSynchronize(l->stream));
     return GNN_OK;
 }
 
-extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output)
+static int readout_combine(gnn_loop *lm, int G, float *out_graph)
+{
+    if (lm->world > 1) {
+        hipLaunchKernelGGL(k_sum_partials, cdiv((int64_t)G * lm->T, 64), 64, 0, lm->stream, G * lm->T, lm->world, lm->ng_part, lm->ng_out);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(out_graph, lm->ng_out, sizeof(float) * (size_t)G * lm->T, hipMemcpyDeviceToHost, lm->stream));
+    HIPCHK(hipStreamSynchronize(lm->stream));
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_readout(const gnn_loop *l, int G, const int32_t *ng_indptr, const int32_t *ng_node,
+                                const float *ng_w, float *out_graph)
+{
+    ARGCHK(l && out_graph, "bad arguments");
+    gnn_loop *lm = const_cast<gnn_loop *>(l);
+    if (lm->comm && lm->comm->grp && lm->world > 1) return gnn_fail(GNN_ERR_STATE, "loopback group: use gnn_loop_readout_group");
+    int rc = readout_partial(lm, G, ng_indptr, ng_node, ng_w);
+    if (rc) return rc;
+    if (lm->world > 1) {       // every rank gets every rank's [G, T] partial (a few KB), then adds them in rank order
+        const size_t cnt = (size_t)G * lm->T;
+        NCCLCHK(g_rccl.AllGather(lm->ng_part + cnt * lm->rank, lm->ng_part, cnt, NCCL_FLOAT32, lm->comm->nccl, lm->stream));
+    }
+    return readout_combine(lm, G, out_graph);
+}
+
+extern "C" int gnn_loop_readout_group(gnn_loop **loops, int n, int G, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w,
+                                      float *out_graph)
+{
+    ARGCHK(loops && n >= 1 && out_graph, "bad arguments");
+    for (int r = 0; r < n; ++r)
+        ARGCHK(loops[r] && loops[r]->comm && loops[r]->comm->grp && loops[r]->comm->grp == loops[0]->comm->grp && loops[r]->world == n && loops[r]->rank == r,
+               "loops must be the %d ranks of one loopback group, in rank order", n);
+    int rc = 0;
+    for (int r = 0; r < n; ++r) if ((rc = readout_partial(loops[r], G, ng_indptr, ng_node, ng_w))) return rc;
+    const size_t cnt = (size_t)G * loops[0]->T;
+    for (int r = 0; r < n; ++r)
+        for (int p = 0; p < n; ++p)
+            if (p != r) HIPCHK(hipMemcpyAsync(loops[p]->ng_part + cnt * r, loops[r]->ng_part + cnt * r, sizeof(float) * cnt, hipMemcpyDeviceToDevice, loops[r]->stream));
+    std::vector<float> first(cnt), other(cnt);
+    for (int r = 0; r < n; ++r) {
+        if ((rc = readout_combine(loops[r], G, r ? other.data() : first.data()))) return rc;
+        if (r && memcmp(first.data(), other.data(), sizeof(float) * cnt) != 0) return gnn_fail(GNN_ERR_STATE, "ranks disagree on the graph readout");
+    }
+    memcpy(out_graph, first.data(), sizeof(float) * cnt);
+    return GNN_OK;
+}
+
+// LGNN.update_graph on the owned rows of `dst` (reference GNN/LGNN.py:227-260); nothing is synchronised here
+static int relabel_own(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output)
 {
     ARGCHK(dst && base && from, "bad arguments");
     ARGCHK(dst->sh == base->sh, "dst must be derived from base");
     if (!from->ran) return gnn_fail(GNN_ERR_STATE, "the source loop has not run");
-    ARGCHK(from->world == 1, "LGNN relabelling of sharded graphs is not supported");
     ARGCHK(from->g->sh == base->sh, "the source loop ran on an unrelated graph");
+    ARGCHK(!base->halo_world, "LGNN relabelling is not available on boundary-exchange shards");
     // edge-based layers put the output on the ARC labels (LGNN.py:253-254), node/graph-based ones on the node labels (:256)
     const bool arc_side = from->edge_mode;
+    ARGCHK(!arc_side || from->world == 1, "edge-based LGNN stacks are single-GPU only");
     const int out_nodes = (get_output && !arc_side) ? from->T : 0, out_arcs = (get_output && arc_side) ? from->T : 0;
     const int extra = (get_state ? from->Ds : 0) + out_nodes;
     ARGCHK(dst->NL == base->base_NL + extra, "dst label width %d != %d + %d", dst->NL, base->base_NL, extra);
     HIPCHK(hipSetDevice(dst->device));
     // base labels are the first base_NL columns of base->nodes only when base is not itself derived
     ARGCHK(base->NL == base->base_NL, "base must be the original (underived) graph (LGNN.py:287)");
-    const int64_t tot = dst->N * dst->NL;
-    hipLaunchKernelGGL(k_relabel, cdiv(tot, 256), 256, 0, from->stream, dst->N, base->NL, base->nodes, from->Ds, from->state[0], from->state[1],
-                       from->kfinal_dev, get_state, from->T, from->out, base->sh->mask, graph_mask_pos(base), out_nodes ? 1 : 0, dst->nodes, dst->NL);
+    const int64_t rows = base->n_rows, off = base->own_off;
+    const int64_t tot = rows * dst->NL;
+    if (tot)
+        hipLaunchKernelGGL(k_relabel, cdiv(tot, 256), 256, 0, from->stream, rows, base->NL, base->nodes + (size_t)off * base->NL, from->Ds,
+                           from->state[0] + (size_t)from->own_off * from->Ds, from->state[1] + (size_t)from->own_off * from->Ds, from->kfinal_dev, get_state, from->T,
+                           from->out, base->sh->mask, graph_mask_pos(base), out_nodes ? 1 : 0, dst->nodes + (size_t)off * dst->NL, dst->NL);
     if (arc_side) {
         ARGCHK(dst->arc_labels_own && dst->arc_labels_orig_own && base->sh->arc_id, "dst must come from gnn_graph_derive_edge");
         ARGCHK(dst->AL == base->base_AL + out_arcs, "dst arc label width %d != %d + %d", dst->AL, base->base_AL, out_arcs);
@@ -1342,8 +1676,41 @@ extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, co
         }
     }
     HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
+extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output)
+{
+    ARGCHK(from, "bad arguments");
+    if (from->comm && from->comm->grp && from->world > 1) return gnn_fail(GNN_ERR_STATE, "loopback group: use gnn_graph_update_labels_group");
+    int rc = relabel_own(dst, base, from, get_state, get_output);
+    if (rc) return rc;
+    if (from->world > 1) {      // every rank relabelled its own rows: all-gather whole shards of the new label rows, in place
+        const size_t cnt = (size_t)from->shard_rows * dst->NL;
+        ARGCHK((int64_t)from->shard_rows * from->world <= dst->nodes_rows, "derived graph too small for the sharded relabelling");
+        NCCLCHK(g_rccl.AllGather(dst->nodes + cnt * from->rank, dst->nodes, cnt, NCCL_FLOAT32, from->comm->nccl, from->stream));
+    }
     HIPCHK(hipStreamSynchronize(from->stream));
     dst->label_version++;
+    return GNN_OK;
+}
+
+extern "C" int gnn_graph_update_labels_group(gnn_graph **dsts, gnn_graph *const *bases, gnn_loop *const *froms, int n, int get_state, int get_output)
+{
+    ARGCHK(dsts && bases && froms && n >= 1, "bad arguments");
+    for (int r = 0; r < n; ++r)
+        ARGCHK(froms[r] && froms[r]->comm && froms[r]->comm->grp && froms[r]->comm->grp == froms[0]->comm->grp && froms[r]->world == n && froms[r]->rank == r,
+               "froms must be the %d ranks of one loopback group, in rank order", n);
+    int rc = 0;
+    for (int r = 0; r < n; ++r) if ((rc = relabel_own(dsts[r], bases[r], froms[r], get_state, get_output))) return rc;
+    for (int r = 0; r < n; ++r) {
+        const size_t cnt = (size_t)froms[r]->shard_rows * dsts[r]->NL;
+        ARGCHK((int64_t)froms[r]->shard_rows * n <= dsts[r]->nodes_rows, "derived graph too small for the sharded relabelling");
+        for (int p = 0; p < n; ++p)
+            if (p != r) HIPCHK(hipMemcpyAsync(dsts[p]->nodes + cnt * r, dsts[r]->nodes + cnt * r, sizeof(float) * cnt, hipMemcpyDeviceToDevice, froms[r]->stream));
+    }
+    HIPCHK(hipStreamSynchronize(froms[0]->stream));
+    for (int r = 0; r < n; ++r) dsts[r]->label_version++;
     return GNN_OK;
 }
 
@@ -1351,6 +1718,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
 {
     if (!l) return GNN_OK;
     (void)hipSetDevice(l->device);
+    if (l->comm && l->comm->grp && l->comm->grp->member[l->rank] == l) l->comm->grp->member[l->rank] = nullptr;
     gnn_train_ctx_free(l);
     gnn_train_arena_free(l);
     for (int b = 0; b < 2; ++b) { (void)hipFree(l->state[b]); (void)hipFree(l->tmp[b]); (void)hipFree(l->otmp[b]); }
@@ -1360,7 +1728,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
     if (l->gate_host) (void)hipHostFree(l->gate_host);
     (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels);
-    (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out);
+    (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out); (void)hipFree(l->ng_part);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
     delete l;
     return GNN_OK;

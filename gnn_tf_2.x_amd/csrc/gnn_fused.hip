@@ -193,8 +193,8 @@ int gnn_fused_prepare(gnn_loop *l)
         rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL,
                              l->inv + l->NLc, IW, nullptr, 1);
         if (rc) return rc;
-        HIPCHK(hipMemcpy2DAsync(l->inv, sizeof(float) * IW, g->nodes + (size_t)g->row_begin * g->NL, sizeof(float) * g->NL,
-                                sizeof(float) * g->NL, (size_t)g->n_rows, hipMemcpyDeviceToDevice, l->stream));
+        rc = gnn_launch_copy_cols(l->stream, g->n_rows, g->NL, g->nodes + (size_t)g->own_off * g->NL, g->NL, l->inv, IW, nullptr, 1);
+        if (rc) return rc;
     }
     return GNN_OK;
 }
@@ -207,12 +207,12 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     if (!make_plan(m, p)) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused path does not cover this net_state");
     const int cur = k & 1, nxt = cur ^ 1, P = l->world;
     GnnFusedArgs a{};
-    a.n_rows = g->n_rows; a.row_begin = g->row_begin;
+    a.n_rows = g->n_rows; a.row_begin = l->own_off;     // replica row of the first owned row
     a.indptr = g->sh->indptr; a.adj_src = g->sh->adj_src; a.adj_w = g->sh->adj_w;
     a.inv = l->inv;
     a.state_cur = l->state[cur];
     a.state_bytes = (int64_t)l->N_pad * l->Ds * (int64_t)sizeof(float);
-    a.state_nxt = l->state[nxt] + (size_t)g->row_begin * l->Ds;
+    a.state_nxt = l->state[nxt] + (size_t)l->own_off * l->Ds;
     a.Ds = l->Ds; a.NLc = l->NLc; a.AL = g->AL; a.IW = 2 * l->NLc + g->AL; a.in_s = l->in_s; a.KP = p.KP; a.kk0 = p.kk0;
     a.vec = (l->Ds % 4 == 0) ? 4 : 1;
     int lpr = 1, lg = 0;
@@ -232,29 +232,38 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.flag_out = l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS;
     a.world = P;
     a.stamps = nullptr;
-    static const int debug = getenv("GNN_FUSED_DEBUG") ? atoi(getenv("GNN_FUSED_DEBUG")) : 0;   // timing experiments only
-    a.wstride = (debug & 1) ? 0 : 1;
-    static const char *stamp_file = getenv("GNN_FUSED_STAMPS");       // diagnostics: dump per-wave phase stamps of body 1
-    static unsigned long long *stamp_buf = nullptr;
+    a.wstride = 1;
     const size_t n_tiles = (size_t)((g->n_rows + 31) / 32);
+#ifdef GNN_DIAG   // diagnostic build only (make DIAG=1): timing experiments and per-wave phase stamps; never in the shipped library
+    static const int debug = getenv("GNN_FUSED_DEBUG") ? atoi(getenv("GNN_FUSED_DEBUG")) : 0;
+    a.wstride = (debug & 1) ? 0 : 1;                                  // 0: every K-step re-reads step 0 (results meaningless)
+    static const char *stamp_file = getenv("GNN_FUSED_STAMPS");       // dump per-wave phase stamps of body 1
+    static unsigned long long *stamp_buf = nullptr;
     const size_t n_waves = n_tiles;
     if (stamp_file && k == 1) {
         if (!stamp_buf) HIPCHK(hipMalloc((void **)&stamp_buf, n_waves * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(stamp_buf, 0, n_waves * 8 * sizeof(unsigned long long), l->stream));
         a.stamps = stamp_buf;
     }
-    static int n_cu = 0;
-    if (!n_cu) {
+#endif
+    static int n_cu_dev[64] = {0};
+    if (l->device < 0 || l->device >= 64) return gnn_fail(GNN_ERR_ARG, "device %d out of range", l->device);
+    if (!n_cu_dev[l->device]) {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, l->device));
-        n_cu = std::max(1, prop.multiProcessorCount);
+        n_cu_dev[l->device] = std::max(1, prop.multiProcessorCount);
     }
+    const int n_cu = n_cu_dev[l->device];
     // one workgroup per CU; small graphs spread their tiles over as many CUs as they have tiles (a tile alone on a CU runs
     // faster than eight sharing its L1 / LDS / SIMDs; the waves without a tile leave at once)
     const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, n_tiles);
     a.tile_ctr = l->tile_ctr + k;
+    int stagger_rounds = 0;
+#ifdef GNN_DIAG
     static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : 0;   // tuning experiments
-    a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_env : 0;   // only when every wave has several tiles to run
+    stagger_rounds = stagger_env;
+#endif
+    a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_rounds : 0;   // only when every wave has several tiles to run
     const size_t lds = lds_bytes(p);
     bool ok = false;
     if (split) {
@@ -265,12 +274,14 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     else if (p.layers == 2) ok = gnn_fused_launch_l2(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     else ok = gnn_fused_launch_l3(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);
+#ifdef GNN_DIAG
     if (a.stamps) {
         std::vector<unsigned long long> host(n_waves * 8);
         HIPCHK(hipStreamSynchronize(l->stream));
         HIPCHK(hipMemcpy(host.data(), stamp_buf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (FILE *f = fopen(stamp_file, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
     }
+#endif
     HIPCHK(hipGetLastError());
     return GNN_OK;
 }

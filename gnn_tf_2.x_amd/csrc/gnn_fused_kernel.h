@@ -860,6 +860,9 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     GnnFusedArgs a = a0;
     asm volatile("" : "+s"(a.Wp[0]), "+s"(a.Wp[1]), "+s"(a.Wp[2]), "+s"(a.bias[0]), "+s"(a.bias[1]), "+s"(a.bias[2]));
     asm volatile("" : "+s"(a.bn_scale), "+s"(a.bn_shift), "+s"(a.state_cur), "+s"(a.state_nxt), "+s"(a.inv), "+s"(a.adj_src), "+s"(a.adj_w));
+#ifndef GNN_DIAG
+#define GNN_STAMP(slot) do { } while (0)
+#else
     unsigned long long *stamp = a.stamps ? a.stamps + ((size_t)tile << 3) : nullptr;
 #define GNN_STAMP(slot)                                                                      \
     do {                                                                                     \
@@ -870,6 +873,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
             __builtin_amdgcn_sched_barrier(0);                                               \
         }                                                                                    \
     } while (0)
+#endif
     GNN_STAMP(0);
 
     // the tile's 33 row pointers go through LDS: the gather re-reads them inside divergent code, where a cross-lane
@@ -956,11 +960,13 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
 template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
 inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
-    static bool raised = false;   // dynamic LDS above 64 KiB has to be requested once per kernel
-    if (!raised) {
+    static bool raised[64] = {false};   // dynamic LDS above 64 KiB has to be requested once per kernel AND device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !raised[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT, SPLIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
+        if (dev >= 0 && dev < 64) raised[dev] = true;
     }
     hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
 }

@@ -621,7 +621,7 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
     if (l->D) {
         if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, tmpl + c_aggn, in_s, nullptr, 1))) return rc;
-        if (N) HIPCHK(hipMemcpy2DAsync(tmpl + c_nodes, sizeof(float) * in_s, g->nodes, sizeof(float) * g->NL, sizeof(float) * g->NL, (size_t)N, hipMemcpyDeviceToDevice, st));
+        if ((rc = gnn_launch_copy_cols(st, N, g->NL, g->nodes, g->NL, tmpl + c_nodes, in_s, nullptr, 1))) return rc;
     }
     // state, condition flags
     float *state = nullptr, *state_old = nullptr;
@@ -663,7 +663,7 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
         float *inp = nullptr, *y = nullptr;
         if ((rc = buf.get(&inp, (size_t)N * in_s))) return rc;
         HIPCHK(hipMemcpyAsync(inp, tmpl, sizeof(float) * (size_t)N * in_s, hipMemcpyDeviceToDevice, st));
-        if (N) HIPCHK(hipMemcpy2DAsync(inp, sizeof(float) * in_s, state, sizeof(float) * Ds, sizeof(float) * Ds, (size_t)N, hipMemcpyDeviceToDevice, st));
+        if ((rc = gnn_launch_copy_cols(st, N, Ds, state, Ds, inp, in_s, nullptr, 1))) return rc;
         if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, state, Ds, Ds, inp + c_aggs, in_s, nullptr, 1))) return rc;
         cx->caches.emplace_back();
         if ((rc = net_forward(st, buf, ns, N, inp, d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)k : nullptr, seed + 7919ull * (uint64_t)(k + 1),

@@ -82,6 +82,8 @@ int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const int32_t *a
  * dst.nodes <- [base.nodes | state of `from` (if get_state) | scatter(mask, output of `from`) (if get_output)].
  * `dst` must have been created by gnn_graph_derive(base, extra) with extra = get_state*Ds + get_output*T. */
 int gnn_graph_derive(const gnn_graph *base, int extra_node_label_dims, gnn_graph **out);
+/* Sharded graphs (full-replica shards): every rank relabels its own rows, then the new label rows are all-gathered (RCCL
+ * communicator: call on every rank; loopback group: gnn_graph_update_labels_group below). */
 int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output);
 /* Edge-based LGNN (reference GNN/LGNN.py:253-254: the output of an edge-based layer widens the ARC labels, its state the
  * node labels).  gnn_graph_set_arc_order gives the original graph what the arc side needs: arc_id [n_arcs] = arc of every
@@ -112,8 +114,10 @@ int gnn_mlp_destroy(gnn_mlp *m);
  *   max_iter, thr  max_iteration, state_threshold (GNN.py:61-62)
  * gnn_loop_set_state0: injected initial state [n_rows owned, state_dim] (the reference draws tf.random.normal(stddev=0.1),
  * GNN.py:262, whose stream cannot be reproduced); NULL draws N(0, 0.1^2) from the engine's own counter RNG with `seed`.
- * gnn_loop_run: runs the whole loop on the device; the only host synchronisation is at its end.  *k_out = number of
- * executed iterations as float (GNN.py:267).  training != 0 is GNN_ERR_UNSUPPORTED (backward pass: SURVEY.md 8f).
+ * gnn_loop_run: runs the whole loop on the device; the host synchronises at its end (and reads one gate every 16 bodies so
+ * that a converged loop stops enqueuing).  *k_out = number of executed iterations as float (GNN.py:267).  This is the
+ * inference Loop (training=False); training != 0 is GNN_ERR_UNSUPPORTED here: the training-mode Loop and its backward pass
+ * are gnn_loop_train_forward / gnn_loop_train_backward / gnn_loop_train_step below.
  */
 int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_output, int state_dim, int max_iter, float threshold,
                     gnn_comm *comm /* NULL: single GPU */, gnn_loop **out);
@@ -193,14 +197,41 @@ int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *avg_iter_ms, 
 int gnn_loop_destroy(gnn_loop *l);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------------------------------------------------
- * Nodes are sharded by contiguous ranges; every iteration ends with one grouped RCCL all-gather of the owned state
- * rows and the owned convergence flag.  The 128-byte id is produced on rank 0 and handed to the other ranks by the
- * caller (file, socket, torch.distributed store ...). */
+ * No reference counterpart: the reference is single-device.  What is sharded is the row-wise work of convergence()
+ * (GNN/GNN.py:223-242: sparse_dense_matmul(adjacency, state) at :234 needs neighbour rows of other ranks) and the global
+ * reduce_any of condition() (:218).  Nodes are sharded by contiguous ranges; every iteration ends with one grouped RCCL
+ * all-gather of the owned state rows (or, for shards created by gnn_graph_create_halo, of the owned BOUNDARY rows only)
+ * and the owned convergence flag.  The 128-byte id is produced on rank 0 and handed to the other ranks by the caller
+ * (file, socket, torch.distributed store ...). */
 int gnn_shard_range(int64_t n_nodes, int rank, int world, int64_t *row_begin, int64_t *n_rows);   /* owned rows of a rank */
 int gnn_comm_unique_id(uint8_t id[128]);
 int gnn_comm_create(const uint8_t id[128], int rank, int world, int device, gnn_comm **out);
 int gnn_comm_allreduce_max(gnn_comm *c, double *value);   /* barrier + max over ranks (bench timing) */
 int gnn_comm_destroy(gnn_comm *c);
+/* Boundary ("halo") exchange.  gnn_halo_plan (host only, needs the CSR-by-destination of the WHOLE graph): slot[v] =
+ * position of node v among the boundary rows of its owner (rows read by another rank), -1 for interior nodes; counts[q] =
+ * boundary rows of rank q; *block = max count.  gnn_graph_create_halo builds rank r's shard in the compact index space
+ *   [0, shard) owned rows | shard + q * block + slot: boundary rows of rank q
+ * (adj_src_replica and the rows of nodes_replica are given in that space; send_rows = ascending owned-row indices of this
+ * rank's boundary rows).  Loops on such a graph all-gather `block` rows per rank and iteration instead of whole shards.
+ * LGNN relabelling and the edge-based readout are not available on halo shards. */
+int gnn_halo_plan(int64_t n_nodes, int world, const int32_t *indptr, const int32_t *adj_src, int32_t *slot /* [n_nodes] */,
+                  int64_t *counts /* [world] */, int64_t *block);
+int gnn_graph_create_halo(int64_t n_nodes_global, int rank, int world, int64_t halo_block, int64_t n_send, const int32_t *send_rows,
+                          int64_t n_arcs, const int32_t *indptr, const int32_t *adj_src_replica, const float *adj_w,
+                          const float *arc_w, const float *arc_labels, int dim_arc_label, const float *nodes_replica,
+                          int dim_node_label, const uint8_t *mask, int device, gnn_graph **out);
+/* In-process LOOPBACK group: `world` communicators on ONE device sharing one stream; the exchange steps become
+ * device-to-device copies between the members' buffers.  It runs the sharded code path (row offsets, padded replicas,
+ * per-rank flag slots, every exchange call site) on a single GPU; used by the parity tests, never for speed.  One loop per
+ * rank and group; the ranks of a group are driven together by the *_group entry points (k, readout: rank 0's values, after
+ * checking that all ranks agree). */
+int gnn_comm_create_loopback(int world, int device, gnn_comm **out /* [world] */);
+int gnn_loop_run_group(gnn_loop **loops, int n, float *k_out);
+int gnn_loop_readout_group(gnn_loop **loops, int n, int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node,
+                           const float *ng_w, float *out_graph);
+int gnn_graph_update_labels_group(gnn_graph **dsts, gnn_graph *const *bases, gnn_loop *const *froms, int n, int get_state,
+                                  int get_output);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,240 @@
+"""The engine's SHARDED path on one GPU: a loopback communicator group (gnn_comm_create_loopback) runs `world` ranks of the
+node-range sharded loop in one process, with the real HIP kernels (row_begin > 0, padded replicas, a short / empty last
+shard, per-rank flag slots, the exchange call sites of the RCCL path) and device-to-device copies in place of RCCL.
+
+Bar: impl 0 / 1 bit-identical to the unsharded run AND to the C oracle (k, owned state rows, outputs); impl 2 with the same k
+and within the fp32-noise tolerance of the unsharded run.  The reference has no counterpart (single device): what is sharded
+is the row-wise work of convergence() (GNN/GNN.py:223-242) and the global reduce_any of condition() (GNN.py:218)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as corc
+from oracle import gnn_oracle as orc
+from util import make_mlp, random_arcs
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    from GNN import _engine
+    return _engine
+
+
+def _graph(rng, n, nl, al, deg=4, mode='average'):
+    arcs = random_arcs(rng, n, deg * n, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    return orc.make_graph_dict(arcs, nodes, mode)
+
+
+def _csr_parts(g):
+    arc_labels = np.asarray(g['arcs'], np.float32)[:, 2:]
+    return g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], arc_labels[g['arcT'][1]]
+
+
+def _sharded_loops(e, g, st, ou, d, max_it, thr, s0, world, impl, halo=False):
+    """One loop per rank of a loopback group.  Returns (comms, graphs, loops, ranges)."""
+    n = g['nodes'].shape[0]
+    indptr, adj_src, adj_w, arc_w, arc_lab = _csr_parts(g)
+    mask = np.logical_and(g['set_mask'], g['output_mask'])
+    comms = e.Comm.loopback(world)
+    mst = e.Mlp(st['weights'], st['activations'], st['batch_normalization'])
+    mou = e.Mlp(ou['weights'], ou['activations'], ou['batch_normalization'])
+    plan = e.halo_plan(n, world, indptr, adj_src) if halo else None
+    graphs, loops, ranges = [], [], []
+    for r in range(world):
+        rb, nr, ip, src, w, aw, al_ = e.shard_csr(n, r, world, indptr, adj_src, adj_w, arc_w, arc_lab)
+        if halo:
+            h = e.shard_halo(n, r, world, indptr, adj_src, g['nodes'], plan)
+            gr = e.Graph.halo(n, r, world, h['block'], h['send_rows'], ip, h['adj_src'], w, aw, al_, h['nodes'], mask[rb:rb + nr])
+        else:
+            gr = e.Graph(n, ip, src, w, aw, al_, g['nodes'], mask[rb:rb + nr], row_begin=rb)
+        lp = e.Loop(gr, mst, mou, d, max_it, thr, comms[r])
+        used = lp.set_impl(impl)
+        assert used == impl or nr == 0          # a rank without rows has nothing to fuse
+        if d:
+            lp.set_state0(s0[rb:rb + nr])
+        graphs.append(gr); loops.append(lp); ranges.append((rb, nr))
+    return comms, graphs, loops, ranges
+
+
+def _collect(loops, ranges, mask):
+    state = np.concatenate([lp.state() for lp in loops])
+    out = np.concatenate([lp.output() for lp in loops])
+    return state, out
+
+
+def _unsharded(e, g, st, ou, d, max_it, thr, s0, impl):
+    indptr, adj_src, adj_w, arc_w, arc_lab = _csr_parts(g)
+    mask = np.logical_and(g['set_mask'], g['output_mask'])
+    gr = e.Graph(g['nodes'].shape[0], indptr, adj_src, adj_w, arc_w, arc_lab, g['nodes'], mask)
+    lp = e.Loop(gr, e.Mlp(st['weights'], st['activations'], st['batch_normalization']),
+                e.Mlp(ou['weights'], ou['activations'], ou['batch_normalization']), d, max_it, thr)
+    lp.set_impl(impl)
+    if d:
+        lp.set_state0(s0)
+    k = lp.run()
+    return k, lp.state(), lp.output()
+
+
+def _case(seed, n, d, nl=3, al=1, hidden=(16,), act='selu', gain=0.6):
+    rng = np.random.default_rng(seed)
+    g = _graph(rng, n, nl, al)
+    ds, nlc = (d if d else nl), (nl if d else 0)
+    st = make_mlp(rng, al + 2 * (ds + nlc), list(hidden) + [ds], act, gain=gain, bn_random=True)
+    ou = make_mlp(rng, ds + nlc, [2], 'softmax', bn_random=True)
+    s0 = (0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None
+    g['set_mask'] = rng.random(n) < 0.8
+    g['output_mask'] = rng.random(n) < 0.7
+    return g, st, ou, s0
+
+
+@pytest.mark.parametrize('halo', [False, True])
+@pytest.mark.parametrize('world', [2, 3, 8])
+@pytest.mark.parametrize('n,d,hidden', [(1000, 8, (16,)), (4099, 64, (128, 128)), (333, 0, (7,))])
+def test_sharded_loop_bit_exact(n, d, hidden, world, halo):
+    """n = 4099 with the BASELINE net (135 -> 128 -> 128 -> 64): short last shard and padding rows; n = 333 on 8 ranks: the
+    last ranks own nothing at all."""
+    e = _engine()
+    g, st, ou, s0 = _case(100 + n + world, n, d, hidden=hidden)
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 30, 0.01, s0)
+    for impl in (1, 0):
+        comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 30, 0.01, s0, world, impl, halo)
+        k = e.Loop.run_group(loops)
+        state, out = _collect(loops, ranges, None)
+        assert k == kc, (impl, k, kc)
+        assert np.array_equal(state, sc), impl
+        assert out.shape == oc.shape and np.array_equal(out, oc), impl
+        k2 = e.Loop.run_group(loops)                               # second run on the same handles (state restored, flags reset)
+        assert k2 == kc and np.array_equal(_collect(loops, ranges, None)[0], sc)
+        for lp in loops: lp.close()
+        for c in comms: c.close()
+    # default arithmetic (impl 2): same k, fp32 rounding noise away from the unsharded run of the same arithmetic
+    comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 30, 0.01, s0, world, 2, halo)
+    k = e.Loop.run_group(loops)
+    state, out = _collect(loops, ranges, None)
+    ku, su, ou_ = _unsharded(e, g, st, ou, d, 30, 0.01, s0, 2)
+    assert k == ku == kc
+    assert np.array_equal(state, su) and np.array_equal(out, ou_)      # same tiles, same arithmetic: identical bits
+    assert np.max(np.abs(state - sc)) < 2e-6 * max(1.0, float(np.max(np.abs(sc))))
+
+
+def test_sharded_large_graph_matches_unsharded():
+    """100k nodes / ~1M arcs, the BASELINE net, 8 ranks: owned rows bit-equal to the unsharded run (impl 1) and to the C oracle."""
+    e = _engine()
+    from GNN import GNN_utils as utils
+    n, d = 100_000, 64
+    s = utils.syntheticGraph(n, 10.0, 3, 1, 2, seed=11)
+    rng = np.random.default_rng(12)
+    st = make_mlp(rng, 1 + 2 * (3 + d), [128, 128, d], 'selu', gain=0.6)
+    ou = make_mlp(rng, 3 + d, [2], 'softmax')
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    arcs = np.concatenate([np.stack([s['src'], s['dst']], 1).astype(np.float32), s['arc_labels']], axis=1)
+    g = dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
+             adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
+    ku, su, ou_ = _unsharded(e, g, st, ou, d, 12, 0.0, s0, 1)
+    for world, halo in ((8, False), (3, True)):
+        comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 12, 0.0, s0, world, 1, halo)
+        k = e.Loop.run_group(loops)
+        state, out = _collect(loops, ranges, None)
+        assert k == ku == 12 and np.array_equal(state, su) and np.array_equal(out, ou_)
+        for lp in loops: lp.close()
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 12, 0.0, s0)
+    assert np.array_equal(su, sc) and np.array_equal(ou_, oc)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_graph_readout(world):
+    """GNNgraphBased readout (GNN.py:331-332) on shards: per-rank partial sums added in rank order.  Graphs that straddle a
+    shard boundary differ from the unsharded fmaf chain by rounding only; graphs inside one shard are bit-identical."""
+    e = _engine()
+    rng = np.random.default_rng(77 + world)
+    n, d, n_graphs = 960, 8, 12
+    g, st, ou, s0 = _case(5 + world, n, d)
+    g['set_mask'] = np.ones(n, bool); g['output_mask'] = np.ones(n, bool)
+    bounds = np.sort(rng.choice(np.arange(1, n), n_graphs - 1, replace=False))
+    sizes = np.diff(np.concatenate([[0], bounds, [n]]))
+    ng_indptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ng_node = np.arange(n, dtype=np.int32)
+    ng_w = np.repeat(1.0 / sizes, sizes).astype(np.float32)
+    comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 20, 0.01, s0, world, 1)
+    k = e.Loop.run_group(loops)
+    got = e.Loop.readout_group(loops, ng_indptr, ng_node, ng_w)
+    kc, sc, on = corc.loop_node(g, st, ou, d, 20, 0.01, s0)
+    node_graph = np.zeros((n, n_graphs), np.float32)
+    for gi in range(n_graphs):
+        node_graph[ng_indptr[gi]:ng_indptr[gi + 1], gi] = ng_w[ng_indptr[gi]]
+    want = corc.readout(node_graph, on)
+    assert k == kc and got.shape == want.shape
+    shard = ((n + world - 1) // world + 31) // 32 * 32
+    inside = np.array([ng_indptr[gi] // shard == (ng_indptr[gi + 1] - 1) // shard for gi in range(n_graphs)])
+    assert inside.any() and not inside.all()
+    assert np.array_equal(got[inside], want[inside])
+    assert np.max(np.abs(got - want)) < 1e-6
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_lgnn_relabelling(world):
+    """LGNN.update_graph (LGNN.py:227-260) on shards: every rank relabels its own rows, the new label rows are exchanged, the
+    next layer runs on them.  Two layers, get_state and get_output both on; bit-equal to the single-GPU stack."""
+    e = _engine()
+    rng = np.random.default_rng(9 + world)
+    n, d, nl, al = 700, 6, 3, 1
+    g, st0, ou0, s0 = _case(21 + world, n, d)
+    nl1 = nl + d + 2
+    st1 = make_mlp(rng, al + 2 * (d + nl1), [16, d], 'selu', gain=0.6, bn_random=True)
+    ou1 = make_mlp(rng, d + nl1, [2], 'softmax', bn_random=True)
+    s1 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    mask = np.logical_and(g['set_mask'], g['output_mask'])
+    indptr, adj_src, adj_w, arc_w, arc_lab = _csr_parts(g)
+
+    def stack(world_):
+        comms = e.Comm.loopback(world_)
+        m = [e.Mlp(x['weights'], x['activations'], True) for x in (st0, ou0, st1, ou1)]
+        bases, derived, l0, l1 = [], [], [], []
+        for r in range(world_):
+            rb, nr, ip, src, w, aw, al_ = e.shard_csr(n, r, world_, indptr, adj_src, adj_w, arc_w, arc_lab)
+            bases.append(e.Graph(n, ip, src, w, aw, al_, g['nodes'], mask[rb:rb + nr], row_begin=rb))
+            l0.append(e.Loop(bases[-1], m[0], m[1], d, 20, 0.01, comms[r]))
+            l0[-1].set_impl(1); l0[-1].set_state0(s0[rb:rb + nr])
+        k0 = e.Loop.run_group(l0)
+        for r in range(world_):
+            derived.append(bases[r].derive(d + 2))
+        e.Graph.update_labels_group(derived, bases, l0, True, True)
+        labels = derived[0].nodes()
+        for r in range(world_):
+            assert np.array_equal(derived[r].nodes(), labels)          # every rank holds the same relabelled graph
+            l0[r].close()                                              # frees the rank's slot in the group
+        for r in range(world_):
+            rb, nr = e.shard_range(n, r, world_)
+            l1.append(e.Loop(derived[r], m[2], m[3], d, 20, 0.01, comms[r]))
+            l1[-1].set_impl(1); l1[-1].set_state0(s1[rb:rb + nr])
+        k1 = e.Loop.run_group(l1)
+        return k0, k1, labels, np.concatenate([lp.state() for lp in l1]), np.concatenate([lp.output() for lp in l1])
+
+    k0, k1, labels, state, out = stack(world)
+    # single-GPU stack through the same C ABI (world 1 loopback group degenerates to plain copies of nothing)
+    gr = e.Graph(n, indptr, adj_src, adj_w, arc_w, arc_lab, g['nodes'], mask)
+    a = e.Loop(gr, e.Mlp(st0['weights'], st0['activations'], True), e.Mlp(ou0['weights'], ou0['activations'], True), d, 20, 0.01)
+    a.set_impl(1); a.set_state0(s0)
+    ka = a.run()
+    dg = gr.derive(d + 2)
+    dg.update_labels(gr, a, True, True)
+    b = e.Loop(dg, e.Mlp(st1['weights'], st1['activations'], True), e.Mlp(ou1['weights'], ou1['activations'], True), d, 20, 0.01)
+    b.set_impl(1); b.set_state0(s1)
+    kb = b.run()
+    assert (k0, k1) == (ka, kb)
+    assert np.array_equal(labels, dg.nodes())
+    assert np.array_equal(state, b.state()) and np.array_equal(out, b.output())
+
+
+def test_loopback_group_errors():
+    e = _engine()
+    g, st, ou, s0 = _case(3, 200, 4)
+    comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, 4, 5, 0.01, s0, 2, 1)
+    with pytest.raises(e.EngineError):
+        loops[0].run()                                   # a member of a group cannot run alone
+    with pytest.raises(ValueError):
+        e.Loop.run_group(loops[::-1])                    # rank order
+    with pytest.raises(ValueError):                      # one loop per rank and group
+        e.Loop(graphs[0], e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 4, 5, 0.01, comms[0])
+    assert e.Loop.run_group(loops) == corc.loop_node(g, st, ou, 4, 5, 0.01, s0)[0]

@@ -67,7 +67,7 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
         ng_csr = (ip, rows.astype(np.int32), ng[rows, cols])
     res = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0 if loss == 'categorical_crossentropy' else 1, ng_csr,
                           dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], masks_state=ms, masks_output=mo,
-                          bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]), max_iter=max_it)
+                          bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]))
     assert res['k'] == ref['k'] and 1 <= res['k'] <= max_it
     assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
     for got, want in list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output'])):
@@ -85,7 +85,7 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
     # engine RNG masks: same call without injected masks must run and give finite numbers with about the right keep rate
     res2 = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0 if loss == 'categorical_crossentropy' else 1, ng_csr,
                            dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], seed=5,
-                           bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]), max_iter=max_it)
+                           bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]))
     assert np.isfinite(res2['loss']) and all(np.isfinite(a).all() for a in res2['grads_state'] + res2['grads_output'])
 
 
@@ -487,7 +487,7 @@ def test_training_forward_stops_at_convergence():
     mst, mou = e.Mlp(st['weights'], st['activations'], False), e.Mlp(ou['weights'], ou['activations'], False)
     loop = e.Loop(graph, mst, mou, d, max_it, 0.02)
     loop.set_state0(s0)
-    res = loop.train_step(mst, mou, None, targets, weights, 0, max_iter=max_it)
+    res = loop.train_step(mst, mou, None, targets, weights, 0)
     assert res['k'] == ref['k']
     assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
     k = ref['k']

@@ -208,3 +208,31 @@ def test_regularizers_penalty_and_gradient():
     with pytest.raises(TypeError):
         bad = MLP(5, [2], 'tanh', 'zeros', 'zeros', kernel_regularizer=lambda x: 0.0, batch_normalization=False)
         regularizers.penalty_and_gradients(bad.dense_layers)
+
+
+def test_halo_plan_on_host():
+    """gnn_halo_plan is host-only: block-diagonal batches sharded at graph boundaries have no boundary rows at all, a ring
+    has one per cut; shard_halo renumbers sources into [own rows | one block of boundary rows per rank]."""
+    from GNN import _engine as e
+    n, world = 256, 4                        # shard = 64
+    src = np.arange(n, dtype=np.int32)
+
+    def csr(dst):
+        order = np.lexsort((src, dst))
+        indptr = np.zeros(n + 1, np.int64)
+        np.add.at(indptr, dst + 1, 1)
+        return np.cumsum(indptr).astype(np.int32), src[order]
+
+    indptr, adj = csr((src // 64) * 64 + (src + 1) % 64)       # four 64-cycles, one per shard
+    slot, counts, block = e.halo_plan(n, world, indptr, adj)
+    assert block == 0 and not counts.any() and (slot == -1).all()
+    indptr, adj = csr((src + 1) % n)                          # one n-cycle: node 64 q - 1 is read by the next rank
+    slot, counts, block = e.halo_plan(n, world, indptr, adj)
+    assert block == 1 and list(counts) == [1, 1, 1, 1]
+    assert sorted(np.nonzero(slot >= 0)[0]) == [63, 127, 191, 255]
+    nodes = np.arange(2 * n, dtype=np.float32).reshape(n, 2)
+    h = e.shard_halo(n, 1, world, indptr, adj, nodes, (slot, counts, block))
+    assert h['row_begin'] == 64 and h['n_rows'] == 64 and list(h['send_rows']) == [63]
+    # row 64 (first owned row of rank 1) reads node 63 = the boundary row of rank 0 -> slot 64 + 0 * 1 + 0; the others are own rows
+    assert h['adj_src'][0] == 64 and list(h['adj_src'][1:]) == list(range(0, 63))
+    assert h['nodes'].shape == (64 + 4, 2) and np.array_equal(h['nodes'][64], nodes[63]) and np.array_equal(h['nodes'][:64], nodes[64:128])
