@@ -244,3 +244,34 @@ def test_graph_based_and_lgnn_oracle():
     ks, state, outs = orc.lgnn_loop(gn, gnns, False, True, False, s0s)
     assert len(ks) == 3 and len(outs) == 3 and state.shape == (gn['nodes'].shape[0], 3)
     assert all(o.shape == (gn['nodes'].shape[0], t) for o in outs)
+
+
+def test_oracle_against_torch_crosscheck_vectors():
+    """tests/golden/torch_crosscheck.npz holds what PyTorch-CPU computed for the TF/Keras ops of the path (generated by
+    tests/golden/make_torch_crosscheck.py in the build container).  Not a reference-held pin (the TF half stays
+    "parity unpinned"), but an independent implementation of the same semantics: constants, formulas, loop control."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'torch_crosscheck.npz'))
+    x = z['ops/x']
+    for act in ['linear', 'relu', 'selu', 'elu', 'tanh', 'sigmoid', 'softmax']:
+        assert np.max(np.abs(orc.activation(x.astype(np.float64), act) - z[f'ops/{act}'])) < 1e-12, act
+        got32 = corc.mlp_forward(x, [np.eye(11, dtype=np.float32), np.zeros(11, np.float32)], [act], False)
+        assert np.max(np.abs(got32 - z[f'ops/{act}']) / np.maximum(1.0, np.abs(z[f'ops/{act}']))) < 3e-6, act     # C restatement, fp32
+    bn = z['ops/bn_params']
+    ident = [np.eye(11), np.zeros(11)] + [bn[0], bn[1], bn[2], bn[3]]
+    assert np.max(np.abs(orc.mlp_forward(x, ident, ['linear'], True, np.float64) - z['ops/bn'])) < 1e-12
+    for name in ['selu_d0', 'tanh_d8', 'sigmoid_d5', 'selu_d16_deep']:
+        d, nl, al, max_it, n_hidden = (int(v) for v in z[f'{name}/cfg'])
+        act, mode = str(z[f'{name}/act']), str(z[f'{name}/mode'])
+        g = orc.make_graph_dict(z[f'{name}/arcs'], z[f'{name}/nodes'], mode)
+        g['set_mask'] = z[f'{name}/set_mask']
+        n_st = 2 * (n_hidden + 1) + 4
+        st = dict(weights=[z[f'{name}/st{i}'] for i in range(n_st)], activations=[act] * (n_hidden + 1), batch_normalization=True)
+        ou = dict(weights=[z[f'{name}/ou{i}'] for i in range(6)], activations=['softmax'], batch_normalization=True)
+        s0 = z[f'{name}/s0'] if d else None
+        k64, s64, o64 = orc.loop_node(g, st, ou, d, max_it, 0.01, s0, np.float64)
+        assert k64 == int(z[f'{name}/f64/k']) and 1 < k64 < max_it
+        assert np.max(np.abs(s64 - z[f'{name}/f64/state'])) < 1e-12 and np.max(np.abs(o64 - z[f'{name}/f64/out'])) < 1e-12
+        for k32, s32, o32 in (orc.loop_node(g, st, ou, d, max_it, 0.01, s0, np.float32), corc.loop_node(g, st, ou, d, max_it, 0.01, s0)):
+            assert k32 == int(z[f'{name}/f32/k'])
+            assert np.max(np.abs(s32 - z[f'{name}/f32/state'])) < 1e-5 and np.max(np.abs(o32 - z[f'{name}/f32/out'])) < 1e-5
