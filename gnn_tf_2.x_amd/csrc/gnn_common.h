@@ -141,6 +141,7 @@ struct gnn_mlp {
     size_t packed_floats = 0;
     int *packed_split = nullptr;        // bf16-piece weight image of the split-arithmetic fused kernel (impl 2)
     size_t packed_split_dwords = 0;
+    int pack_nlc = -1;                  // node-label columns of the concat the split image was laid out for (alignment hole)
     bool pack_dirty = true;             // the images are rebuilt on the next fused use (training rewrites the weights every step)
     uint64_t version = 0;
 };
@@ -223,6 +224,6 @@ void gnn_train_arena_free(gnn_loop *l);
 // gnn_fused.hip
 bool gnn_fused_supported(const gnn_loop *l);
 int gnn_fused_prepare(gnn_loop *l);
-int gnn_fused_pack(gnn_mlp *m);
+int gnn_fused_pack(gnn_mlp *m, int nlc);
 int gnn_fused_iteration(gnn_loop *l, int k);
 void gnn_fused_release(gnn_mlp *m);

@@ -18,7 +18,8 @@ struct GnnFusedArgs {
     float *state_nxt;        // owned rows
     int64_t state_bytes;     // size of the replica state_cur points to
     // shapes
-    int Ds, NLc, AL, IW, in_s, KP, lpr, lpr_log2, vec, kk0;
+    // in_s: columns of the LDS tile in use (concat width + alignment hole); c_aggs: first column of the aggregated-state block
+    int Ds, NLc, AL, IW, in_s, c_aggs, KP, lpr, lpr_log2, vec, kk0;
     // layers: packed weights [kk][lane][tiles of the layer], biases padded to whole tiles
     const float *Wp[GNN_FUSED_MAXL];
     const float *bias[GNN_FUSED_MAXL];
@@ -35,6 +36,11 @@ struct GnnFusedArgs {
     // of K = 16 chunks of layer 0
     const int *Ws[GNN_FUSED_MAXL];
     int chunks0;
+    // the same image through one buffer descriptor: base pointer, size and the byte offset of every layer, so that the weight
+    // loads of the unrolled layers are buffer_load(rsrc, lane * 16, scalar offset) without any per-load vector address arithmetic
+    const int *Ws_base;
+    int ws_bytes, ws_off[GNN_FUSED_MAXL];
+    int variant;             // tuning switches (bit 0: raised wave priority during the gather); fixed in the shipped build
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;
 };

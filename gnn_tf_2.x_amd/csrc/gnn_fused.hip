@@ -18,6 +18,10 @@ constexpr int K_SLACK = 8;      // zero K-steps after the layer-0 block: the pip
 
 struct FusedPlan {
     int layers = 0, NT = 0, NTL = 0, KP = 0, kk0 = 0, act = 0;
+    // split arithmetic, state width 64 (the tuned shape): the LDS tile is laid out for 16-byte accesses - rows 16-byte aligned
+    // (KPs a multiple of 4 with KPs / 4 odd: ds_read_b128 down a column stays bank-conflict free) and the aggregated-state block
+    // starting on a multiple of 4 columns, i.e. after a hole of `pad` zero columns behind [state | nodes]
+    int pad = 0, KPs = 0;
     int nt[MAXL] = {0, 0, 0};       // tiles of each layer's output
     int kk[MAXL] = {0, 0, 0};       // K-steps of each layer
     size_t w_off[MAXL] = {0, 0, 0}, b_off[MAXL] = {0, 0, 0}, bn_off = 0, total = 0;
@@ -26,11 +30,13 @@ struct FusedPlan {
     size_t s_off[MAXL] = {0, 0, 0}, s_total = 0;
 };
 
+constexpr int GNN_FUSED_VARIANT_DEFAULT = 1;      // bit 0: raised wave priority during the gather (measured: -1 %)
+constexpr int GNN_FUSED_SPREAD_DEFAULT = 20;      // start-up spread: every wave waits 0 .. 20 x 8k cycles before its first tile (-3 %)
 constexpr int S_SLACK = 2;      // zero chunks after the layer-0 block of the split image (layer0_split looks two chunks ahead)
 
 int round_tiles(int width) { return width <= 32 ? 1 : (width <= 64 ? 2 : 4); }
 
-bool make_plan(const gnn_mlp *m, FusedPlan &p)
+bool make_plan(const gnn_mlp *m, int nlc, FusedPlan &p)
 {
     if (m->n_layers < 1 || m->n_layers > MAXL) return false;
     p.layers = m->n_layers;
@@ -61,9 +67,16 @@ bool make_plan(const gnn_mlp *m, FusedPlan &p)
     p.bn_off = off;
     off += 2 * 32 * (size_t)p.NTL;
     p.total = off;
+    const int ds = m->dims.back();
+    p.pad = ds == 64 ? (4 - (ds + nlc) % 4) % 4 : 0;
+    p.KPs = p.KP;
+    if (ds == 64) {
+        p.KPs = (std::max(2 * p.kk0, (m->dims[0] + p.pad + 15) / 16 * 16) + 3) / 4 * 4;
+        if ((p.KPs / 4) % 2 == 0) p.KPs += 4;
+    }
     size_t soff = 0;
     for (int l = 0; l < p.layers; ++l) {
-        p.chunks[l] = l == 0 ? (m->dims[0] + 15) / 16 : 2 * p.NT;
+        p.chunks[l] = l == 0 ? (m->dims[0] + p.pad + 15) / 16 : 2 * p.NT;
         p.s_off[l] = soff;
         soff += (size_t)(p.chunks[l] + (l == 0 ? S_SLACK : 0)) * p.nt[l] * 3 * 256;
     }
@@ -75,7 +88,7 @@ bool make_plan(const gnn_mlp *m, FusedPlan &p)
 size_t lds_bytes(const FusedPlan &p)
 {
     // ... and the last layer's bias / BatchNormalization scale / shift (3 x 32 NTL floats) and the hidden biases (2 x 32 NT)
-    return (size_t)GNN_FUSED_WAVES * 32 * p.KP * sizeof(float) + 128 + GNN_FUSED_WAVES * 36 * sizeof(int) + (3 + 2) * 32 * 4 * sizeof(float) + 16;
+    return (size_t)GNN_FUSED_WAVES * 32 * std::max(p.KP, p.KPs) * sizeof(float) + 128 + GNN_FUSED_WAVES * 36 * sizeof(int) + (3 + 2) * 32 * 4 * sizeof(float) + 16;
 }
 
 }   // namespace
@@ -83,10 +96,12 @@ size_t lds_bytes(const FusedPlan &p)
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-int gnn_fused_pack(gnn_mlp *m)
+int gnn_fused_pack(gnn_mlp *m, int nlc)
 {
     FusedPlan p;
-    if (!make_plan(m, p)) { gnn_fused_release(m); return GNN_OK; }
+    if (!make_plan(m, nlc, p)) { gnn_fused_release(m); return GNN_OK; }
+    m->pack_nlc = nlc;
+    const int lab = m->dims.back() + nlc;      // [state | nodes] columns in front of the alignment hole
     std::vector<float> img(p.total, 0.0f);
     std::vector<uint32_t> simg(p.s_total, 0u);
     std::vector<float> W, b;
@@ -112,7 +127,8 @@ int gnn_fused_pack(gnn_mlp *m)
                 for (int lane = 0; lane < 64; ++lane)
                     for (int i = 0; i < 8; ++i) {
                         const int h = lane >> 5, r = 8 * (c & 1) + i;
-                        const int k = l == 0 ? 16 * c + 8 * h + i : 32 * (c >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        int k = l == 0 ? 16 * c + 8 * h + i : 32 * (c >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (l == 0 && p.pad) k = k < lab ? k : (k < lab + p.pad ? n_in : k - p.pad);   // LDS column -> concat column (hole: zero)
                         const int j = 32 * jt + (lane & 31);
                         float v = (k < n_in && j < n_out) ? W[(size_t)k * n_out + j] : 0.0f;
                         for (int pc = 0; pc < 3; ++pc) {          // truncation split: v == p0 + p1 + p2 exactly
@@ -161,9 +177,9 @@ void gnn_fused_release(gnn_mlp *m)
 bool gnn_fused_supported(const gnn_loop *l)
 {
     FusedPlan p;
-    if (!make_plan(l->st, p)) return false;
-    if (l->st->pack_dirty) {            // weights changed since the images were built
-        if (gnn_fused_pack(l->st) != GNN_OK) return false;
+    if (!make_plan(l->st, l->NLc, p)) return false;
+    if (l->st->pack_dirty || l->st->pack_nlc != l->NLc) {            // weights (or the concat layout) changed since the images were built
+        if (gnn_fused_pack(l->st, l->NLc) != GNN_OK) return false;
         l->st->pack_dirty = false;
     }
     if (!l->st->packed) return false;
@@ -204,7 +220,8 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     const gnn_graph *g = l->g;
     const gnn_mlp *m = l->st;
     FusedPlan p;
-    if (!make_plan(m, p)) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused path does not cover this net_state");
+    if (!make_plan(m, l->NLc, p)) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused path does not cover this net_state");
+    if (m->pack_nlc != l->NLc) return gnn_fail(GNN_ERR_STATE, "weight image laid out for another label width");
     const int cur = k & 1, nxt = cur ^ 1, P = l->world;
     GnnFusedArgs a{};
     a.n_rows = g->n_rows; a.row_begin = l->own_off;     // replica row of the first owned row
@@ -213,7 +230,10 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.state_cur = l->state[cur];
     a.state_bytes = (int64_t)l->N_pad * l->Ds * (int64_t)sizeof(float);
     a.state_nxt = l->state[nxt] + (size_t)l->own_off * l->Ds;
-    a.Ds = l->Ds; a.NLc = l->NLc; a.AL = g->AL; a.IW = 2 * l->NLc + g->AL; a.in_s = l->in_s; a.KP = p.KP; a.kk0 = p.kk0;
+    const bool split = l->impl_req == 2;
+    const int pad = split ? p.pad : 0;
+    a.Ds = l->Ds; a.NLc = l->NLc; a.AL = g->AL; a.IW = 2 * l->NLc + g->AL; a.in_s = l->in_s + pad; a.c_aggs = l->Ds + l->NLc + pad;
+    a.KP = split ? p.KPs : p.KP; a.kk0 = p.kk0;
     a.vec = (l->Ds % 4 == 0) ? 4 : 1;
     int lpr = 1, lg = 0;
     while ((lpr * a.vec < l->Ds || lpr < 2) && lpr < 64) { lpr <<= 1; ++lg; }
@@ -222,9 +242,12 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         a.Wp[i] = m->packed + p.w_off[i];
         a.bias[i] = m->packed + p.b_off[i];
     }
-    const bool split = l->impl_req == 2;
     for (int i = 0; i < p.layers; ++i) a.Ws[i] = m->packed_split + p.s_off[i];
     a.chunks0 = p.chunks[0];
+    a.Ws_base = m->packed_split;
+    a.ws_bytes = (int)(p.s_total * sizeof(uint32_t));
+    for (int i = 0; i < p.layers; ++i) a.ws_off[i] = (int)(p.s_off[i] * sizeof(uint32_t));
+    a.variant = GNN_FUSED_VARIANT_DEFAULT;
     a.bn_scale = m->has_bn ? m->packed + p.bn_off : nullptr;
     a.bn_shift = m->has_bn ? m->packed + p.bn_off + 32 * p.NTL : nullptr;
     a.thr = l->thr;
@@ -234,6 +257,10 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.stamps = nullptr;
     a.wstride = 1;
     const size_t n_tiles = (size_t)((g->n_rows + 31) / 32);
+#ifdef GNN_DIAG
+    static const int variant_env = getenv("GNN_FUSED_VARIANT") ? atoi(getenv("GNN_FUSED_VARIANT")) : GNN_FUSED_VARIANT_DEFAULT;
+    a.variant = variant_env;
+#endif
 #ifdef GNN_DIAG   // diagnostic build only (make DIAG=1): timing experiments and per-wave phase stamps; never in the shipped library
     static const int debug = getenv("GNN_FUSED_DEBUG") ? atoi(getenv("GNN_FUSED_DEBUG")) : 0;
     a.wstride = (debug & 1) ? 0 : 1;                                  // 0: every K-step re-reads step 0 (results meaningless)
@@ -258,9 +285,9 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     // faster than eight sharing its L1 / LDS / SIMDs; the waves without a tile leave at once)
     const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, n_tiles);
     a.tile_ctr = l->tile_ctr + k;
-    int stagger_rounds = 0;
+    int stagger_rounds = GNN_FUSED_SPREAD_DEFAULT;
 #ifdef GNN_DIAG
-    static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : 0;   // tuning experiments
+    static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : GNN_FUSED_SPREAD_DEFAULT;   // tuning experiments
     stagger_rounds = stagger_env;
 #endif
     a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_rounds : 0;   // only when every wave has several tiles to run
