@@ -73,21 +73,71 @@ def rendezvous_id(rank, world, engine):
         return f.read(), path
 
 
-def cpu_baseline(s, st, ou, state0, d, iters):
-    """The plain-C restatement of the TF2 op sequence (oracle/gnn_oracle.c: CSR SpMM -> materialised concat -> Dense x3 ->
-    BatchNormalization -> norm check), OpenMP over all host cores, on a bounded sample: the full graph, `iters` iterations."""
-    from oracle import c_oracle
+def oracle_graph(s):
     n = s['n_nodes']
     arcs = np.concatenate([np.stack([s['src'], s['dst']], 1).astype(np.float32), s['arc_labels']], axis=1)
-    g = dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
-             adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
+    return dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
+                adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
+
+
+def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0):
+    """The plain-C restatement of the TF2 op sequence (oracle/gnn_oracle.c: CSR SpMM -> materialised concat -> Dense x3 ->
+    BatchNormalization -> norm check), OpenMP over all host cores, on a bounded sample: the full graph, `iters` iterations;
+    a second figure with the sparse products on ONE thread (TensorFlow's CPU SparseTensorDenseMatMul is believed to be
+    single-threaded); and, as the checker it is, the float64 oracle against both GPU arithmetic modes at the depth
+    of the workload on a 50,000-node graph of the same generator (fp32-noise equivalence of the default path, measured)."""
+    from oracle import c_oracle, gnn_oracle
+    n = s['n_nodes']
+    g = oracle_graph(s)
     c_oracle.loop_node(g, st, ou, d, 1, 0.0, state0)     # warm-up (page faults, thread pool)
     t = time.perf_counter()
     k, _, _ = c_oracle.loop_node(g, st, ou, d, iters, 0.0, state0)
     dt = time.perf_counter() - t
-    return dict(value=n * k / dt, unit='node-state-updates/s', cores=c_oracle.num_threads(), kind='port',
-                sample=f'full 1M-node graph, {int(k)} iterations + readout, C restatement of the TF2 op sequence '
-                       f'(not TensorFlow itself), OpenMP, {dt:.1f} s')
+    c_oracle.set_spmm_single_thread(True)
+    t1 = time.perf_counter()
+    k1, _, _ = c_oracle.loop_node(g, st, ou, d, max(1, iters // 4), 0.0, state0)
+    dt1 = time.perf_counter() - t1
+    c_oracle.set_spmm_single_thread(False)
+    out = dict(value=n * k / dt, unit='node-state-updates/s', cores=c_oracle.num_threads(), kind='port',
+               sample=f'full 1M-node graph, {int(k)} iterations + readout, C restatement of the TF2 op sequence '
+                      f'(not TensorFlow itself), OpenMP, {dt:.1f} s',
+               single_thread_spmm={'value': n * k1 / dt1, 'sample': f'{int(k1)} iterations, sparse products on 1 thread, dense layers on '
+                                                                     f'{c_oracle.num_threads()}, {dt1:.1f} s'})
+    if engine is not None:
+        from GNN import GNN_utils as utils
+        n2, bodies = 50_000, 30
+        s2 = utils.syntheticGraph(n2, 10.0, 3, 1, 2, seed=20261003)
+        rng = np.random.default_rng(7)
+        s02 = (0.1 * rng.standard_normal((n2, d))).astype(np.float32)
+        k64, s64, o64 = gnn_oracle.loop_node(oracle_graph(s2), st, ou, d, bodies, 0.0, s02, np.float64)
+        graph = engine.Graph(n2, s2['indptr'], s2['adj_src'], s2['adj_w'], s2['arc_w'], s2['arc_labels_csr'], s2['nodes'], np.ones(n2, np.uint8), device=device)
+        mst = engine.Mlp(st['weights'], st['activations'], True, device=device)
+        mou = engine.Mlp(ou['weights'], ou['activations'], True, device=device)
+        dist = {}
+        for impl, name in ((1, 'exact_fp32_chain'), (2, 'default_split_bf16')):
+            lp = engine.Loop(graph, mst, mou, d, bodies, 0.0)
+            lp.set_impl(impl)
+            lp.set_state0(s02)
+            lp.run()
+            dist[name + '_max_abs_state_error_vs_float64'] = float(np.max(np.abs(lp.state() - s64)))
+            dist[name + '_max_abs_output_error_vs_float64'] = float(np.max(np.abs(lp.output() - o64)))
+            lp.close()
+        dist['graph'] = f'{n2} nodes / {s2["n_arcs"]} arcs, same generator and weights, {bodies} bodies (threshold 0), max |state| {float(np.max(np.abs(s64))):.2f}'
+        out['fp32_noise_check'] = dist
+    return out
+
+
+def profile_figures():
+    """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC passes of this command
+    (tools/profile.sh + tools/collect_profile.py -> profiles/<round>_pmc.json); None when no profile is committed."""
+    for tag in ('r02', 'r01'):
+        path = os.path.join(ROOT, 'profiles', f'{tag}_pmc.json')
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            d['source'] = f'profiles/{tag}_pmc.json'
+            return d
+    return None
 
 
 def main():
@@ -182,6 +232,18 @@ def main():
         one.close()
         del final_exact, final_default, s2
 
+    # the reference builds the label aggregates (GNN.py:259, :263) in every Loop(); the engine keeps them between Loops until
+    # the labels change.  Cold figure: the same Loop with the kept aggregates dropped before each call.
+    cold_ms = None
+    if world == 1:
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(2):
+            loop.drop_cached_aggregates()
+            loop.run()
+        barrier()
+        cold_ms = 1e3 * (time.perf_counter() - t3) / 2
+
     # boundary-inclusive rate (never `value`): host state0 in, host state + output back, one Loop (DESIGN.md "Measurement")
     t1 = time.perf_counter()
     loop.set_state0(state0[rb:rb + nr])
@@ -197,11 +259,10 @@ def main():
         # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc run of this same command
         # (tools/profile.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed under profiles/
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if world == 1 and impl_used == 2 and args.nodes == 1_000_000 and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
-            traffic_src = 'profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)'
+        pf = profile_figures() if (world == 1 and impl_used == 2 and args.nodes == 1_000_000) else None
+        if pf:
+            traffic = pf.get('hbm_bytes_per_launch')
+            traffic_src = pf['source'] + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE doubled as the guide prescribes for gfx950)'
         line = {
             'metric': 'node-state-updates/sec (nodes x iters / s), 1M-node synthetic graph',
             'value': updates / elapsed, 'unit': 'node-state-updates/s', 'n_gpus': world, 'steps': args.steps,
@@ -209,7 +270,8 @@ def main():
             'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'synthetic randomGraph-recipe graph, N={n} nodes, E={e} arcs, state_dim=64, '
                                    f'net_state 135->128->128->64 selu+BN, net_output 67->2 softmax+BN, '
-                                   f'max_iter={args.max_iter}, threshold=0 (all iterations run)',
+                                   f'max_iter={args.max_iter}, threshold=0 (all iterations run); the loop-invariant label aggregates '
+                                   f'(GNN.py:259, :263; 0.2 ms) are kept between Loops until the labels change, see cold_aggregates_ms_per_step',
                        'iterations_per_step': k_total / args.steps,
                        'parallelism': f'node-range shards x{world}, RCCL all-gather of state rows per iteration' if world > 1 else 'single GPU',
                        'impl': {2: 'fused gather+MLP kernel, dense layers on the bf16 MFMA with fp32 operands cut into 3 exact bf16 '
@@ -217,14 +279,18 @@ def main():
                                 1: 'fused gather+MLP kernel, dense layers on the f32 MFMA (bit-identical to the oracle)',
                                 0: 'one kernel per TF op (unfused)'}[impl_used],
                        'exact_f32_mfma_path': exact,
+                       'cold_aggregates_ms_per_step': cold_ms,
                        'pcie_inclusive_updates_per_s': nr * k_e2e / e2e_s},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'gnn_fused_iteration' if impl_used else 'spmm + dense x3 + check (sum of the per-iteration kernels)',
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': kernel_ms},
         }
+        if pf:      # counters of the same kernel from the committed PMC passes (north_star: HBM GB/s and MFMA-busy against gfx950 peak)
+            line['roofline'].update({k: pf[k] for k in ('mfma_busy_pct', 'valu_busy_pct', 'lds_bank_conflict_share', 'valu_insts_per_tile',
+                                                        'effective_clock_ghz', 'profiled_avg_launch_ms') if k in pf})
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters)
+            line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters, engine, local_rank)
         print(json.dumps(line), flush=True)
     if comm:
         barrier()

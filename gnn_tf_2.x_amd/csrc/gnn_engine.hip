@@ -1147,6 +1147,15 @@ extern "C" int gnn_loop_set_impl(gnn_loop *l, int impl, int *used)
     return GNN_OK;
 }
 
+// forget the loop-invariant label aggregates (GNN.py:259, :263) kept from the previous run: the next run rebuilds them, as every
+// Loop() call of the reference does
+extern "C" int gnn_loop_drop_cached_aggregates(gnn_loop *l)
+{
+    ARGCHK(l, "loop is NULL");
+    l->inv_version = 0;
+    return GNN_OK;
+}
+
 extern "C" int gnn_loop_set_profiling(gnn_loop *l, int enable)
 {
     ARGCHK(l, "loop is NULL");

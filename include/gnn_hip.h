@@ -193,6 +193,10 @@ int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);
 /* per-kernel HIP-event timing of the last gnn_loop_run when profiling was enabled:
  * avg_iter_ms = mean duration of the per-iteration kernel(s), total_ms = whole loop on the stream. */
 int gnn_loop_set_profiling(gnn_loop *l, int enable);
+/* The label aggregates ArcNode^T . arc labels and Adjacency^T . node labels (GNN/GNN.py:259, :263) do not depend on the state:
+ * the fused path builds them on the first run and keeps them until the labels change (gnn_graph_update_labels).  This call
+ * drops them, so that the next gnn_loop_run pays for them like every Loop() of the reference does (bench.py: cold figure). */
+int gnn_loop_drop_cached_aggregates(gnn_loop *l);
 int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *avg_iter_ms, int *n_iter_timed);
 int gnn_loop_destroy(gnn_loop *l);
 

@@ -155,3 +155,8 @@ def loop_node(g: dict, net_state: dict, net_output: dict, state_vect_dim: int, m
 
 def num_threads() -> int:
     return int(lib().orc_num_threads())
+
+
+def set_spmm_single_thread(on: bool) -> None:
+    """Timing knob of the CPU baseline: sparse products on one thread (see gnn_oracle.c)."""
+    lib().orc_set_spmm_single_thread(C.c_int(bool(on)))

@@ -73,11 +73,16 @@ static inline float act_scalar(float v, int act)
     }
 }
 
+/* Timing knob for the CPU baseline of bench.py: TensorFlow's CPU SparseTensorDenseMatMul is believed to be
+ * single-threaded, so the baseline is reported a second time with the sparse products on ONE thread (dense layers on all). */
+static int g_spmm_single_thread = 0;
+void orc_set_spmm_single_thread(int on) { g_spmm_single_thread = on != 0; }
+
 /* out[r] = sum_e val[e] * dense[inner[e]] over the stored entries of row r, in order */
 void orc_spmm(int64_t n_rows, const int32_t *indptr, const int32_t *inner, const float *val, const float *dense,
               int width, float *out, int64_t ld_out)
 {
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(dynamic, 256) if (!g_spmm_single_thread)
     for (int64_t r = 0; r < n_rows; ++r) {
         float *o = out + r * ld_out;
         for (int c = 0; c < width; ++c) o[c] = 0.0f;

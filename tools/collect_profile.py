@@ -18,11 +18,29 @@ f, w = pmc(d + 'pmc_fetch/pmc_counter_collection.csv'), pmc(d + 'pmc_write/pmc_c
 k = [n for n in f if 'k_fused' in n and 'true' in n][0]
 avg = lambda a: sum(a) / len(a)
 fetch, write = avg(f[k]['FETCH_SIZE']), avg(w[k]['WRITE_SIZE'])
-out = json.load(open(f'profiles/{tag}_traffic.json'))
+import os
+out = json.load(open(f'profiles/{tag}_traffic.json')) if os.path.exists(f'profiles/{tag}_traffic.json') else {}
 out.update({'kernel': k, 'FETCH_SIZE_KB_per_launch': fetch, 'WRITE_SIZE_KB_per_launch': write, 'TCC_HIT_per_launch': avg(w[k]['TCC_HIT_sum']),
             'TCC_MISS_per_launch': avg(w[k]['TCC_MISS_sum']), 'hbm_bytes_per_launch': 2 * fetch * 1024 + write * 1024,
             'launches_averaged': len(f[k]['FETCH_SIZE'])})
 json.dump(out, open(f'profiles/{tag}_traffic.json', 'w'), indent=1)
+# counter-derived figures bench.py copies into its `roofline` object
+sq, inst = pmc(d + 'pmc_sq/pmc_counter_collection.csv'), pmc(d + 'pmc_inst/pmc_counter_collection.csv')
+ks, ki = [n for n in sq if 'k_fused' in n and 'true' in n][0], [n for n in inst if 'k_fused' in n and 'true' in n][0]
+cycles = avg(f[k]['GRBM_GUI_ACTIVE']) / 8.0            # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+rows_stats = [r for r in csv.DictReader(open(d + 'stats/stats_kernel_stats.csv')) if r['Name'] == k]
+prof_ms = float(rows_stats[0]['AverageNs']) / 1e6 if rows_stats else None
+n_tiles = 31250
+fig = {'kernel': k, 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'],
+       'mfma_busy_pct': 100.0 * avg(sq[ks]['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024 * cycles),
+       'valu_busy_pct': 100.0 * 4.0 * avg(sq[ks]['SQ_ACTIVE_INST_VALU']) / (1024 * cycles),
+       'lds_bank_conflict_share': avg(inst[ki]['SQ_LDS_BANK_CONFLICT']) / avg(inst[ki]['SQ_ACTIVE_INST_LDS']),
+       'valu_insts_per_tile': avg(inst[ki]['SQ_INSTS_VALU']) / n_tiles, 'mfma_insts_per_tile': avg(inst[ki]['SQ_INSTS_MFMA']) / n_tiles,
+       'effective_clock_ghz': cycles / (prof_ms * 1e6) if prof_ms else None, 'profiled_avg_launch_ms': prof_ms,
+       'definitions': 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles); valu_busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / '
+                      'the same; kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS; '
+                      'per launch averages over all launches of the kernel in `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`'}
+json.dump(fig, open(f'profiles/{tag}_pmc.json', 'w'), indent=1)
 shutil.copy(d + 'summary.txt', f'profiles/{tag}_rocprofv3_summary.txt')
 shutil.copy(d + 'stats/stats_kernel_stats.csv', f'profiles/{tag}_kernel_stats.csv')
 shutil.copy(f'gpurun_out/bench_{tag}.json', f'profiles/{tag}_bench_1gpu.json')
