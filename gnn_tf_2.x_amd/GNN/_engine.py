@@ -19,7 +19,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loss_grad',
-           'gnn_loop_set_impl', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
+           'gnn_loop_set_impl', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
            'gnn_comm_create_loopback', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
 
@@ -507,6 +507,12 @@ class Loop:
         used = C.c_int(0)
         _check(lib().gnn_loop_set_impl(self._h, C.c_int(impl), C.byref(used)))
         return used.value
+
+    def set_persistent(self, enable: bool) -> bool:
+        """gnn_loop_set_persistent: allow / forbid the one-launch-per-Loop path of small graphs; returns whether it will be used."""
+        used = C.c_int(0)
+        _check(lib().gnn_loop_set_persistent(self._h, C.c_int(bool(enable)), C.byref(used)))
+        return bool(used.value)
 
     def drop_cached_aggregates(self):
         _check(lib().gnn_loop_drop_cached_aggregates(self._h))

@@ -1109,10 +1109,11 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
         rc = dev_alloc(&l->state[b], (size_t)l->N_pad * Ds);
         if (!rc && hipMemset(l->state[b], 0, sizeof(float) * (size_t)l->N_pad * Ds) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "memset");
     }
-    if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS);
+    if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS + 4);   // + barrier counter / status of the persistent loop
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 1);
     if (!rc) rc = dev_alloc(&l->tile_ctr, ((size_t)max_iter + 1 + 3) & ~(size_t)3);
-    if (!rc && hipHostMalloc((void **)&l->kfinal_host, sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
+    if (!rc && hipHostMalloc((void **)&l->kfinal_host, 2 * sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
+    if (!rc) l->kfinal_host[1] = 0;
     if (!rc && hipHostMalloc((void **)&l->gate_host, sizeof(int) * (size_t)world * GNN_FLAG_WORDS) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!edge_width) {      // the edge-based buffers are sized in gnn_loop_set_edge_readout
         if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
@@ -1153,6 +1154,15 @@ extern "C" int gnn_loop_drop_cached_aggregates(gnn_loop *l)
 {
     ARGCHK(l, "loop is NULL");
     l->inv_version = 0;
+    return GNN_OK;
+}
+
+// small graphs run all bodies of a Loop inside one persistent launch (gnn_small.hip); enable = 0 keeps to one launch per body
+extern "C" int gnn_loop_set_persistent(gnn_loop *l, int enable, int *used)
+{
+    ARGCHK(l, "loop is NULL");
+    l->small_disabled = enable == 0;
+    if (used) *used = gnn_small_supported(l) ? 1 : 0;
     return GNN_OK;
 }
 
@@ -1359,13 +1369,15 @@ static int loop_gate_closed(gnn_loop *l, int k, bool *closed)
 }
 
 // k, apply_filters + net_output on the owned masked rows (GNN.py:275-279)
-static int loop_finish(gnn_loop *l)
+static int loop_finish(gnn_loop *l, bool finalize)
 {
     gnn_graph *g = l->g;
     hipStream_t st = l->stream;
     int rc = 0;
-    hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, l->world, l->max_iter, l->kfinal_dev);
-    HIPCHK(hipGetLastError());
+    if (finalize) {        // (the persistent small-graph loop has written k itself)
+        hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, l->world, l->max_iter, l->kfinal_dev);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     const float *own0 = l->state[0] + (size_t)l->own_off * l->Ds, *own1 = l->state[1] + (size_t)l->own_off * l->Ds;
     const float *nodes_own = g->nodes + (size_t)g->own_off * g->NL;
@@ -1456,12 +1468,18 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
         fused[r] = f;
     }
     const int max_iter = ls[0]->max_iter;
+    // small graphs: the initial state, the first condition and every body inside ONE persistent launch (gnn_small.hip)
+    const bool small = n == 1 && fused[0] && gnn_small_supported(ls[0]);
     for (int r = 0; r < n; ++r) {
         HIPCHK(hipEventRecord(ls[r]->ev_total[0], ls[r]->stream));
-        if ((rc = loop_begin(ls[r], fused[r]))) return rc;
+        if (!small && (rc = loop_begin(ls[r], fused[r]))) return rc;
     }
-    for (int r = 0; r < n; ++r) if ((rc = loop_exchange(ls[r], 0, 0))) return rc;
-    for (int k = 0; k < max_iter; ++k) {
+    for (int r = 0; r < n && !small; ++r) if ((rc = loop_exchange(ls[r], 0, 0))) return rc;
+    if (small) {
+        ls[0]->kfinal_host[1] = 0;
+        if ((rc = gnn_small_run(ls[0]))) return rc;
+    }
+    for (int k = 0; k < max_iter && !small; ++k) {
         for (int r = 0; r < n; ++r) if ((rc = loop_body(ls[r], k, fused[r]))) return rc;
         for (int r = 0; r < n; ++r)
             if ((rc = loop_exchange(ls[r], (k & 1) ^ 1, (size_t)(k + 1) * ls[r]->world * GNN_FLAG_WORDS))) return rc;
@@ -1476,10 +1494,14 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
         }
     }
     for (int r = 0; r < n; ++r) {
-        if ((rc = loop_finish(ls[r]))) return rc;
+        if ((rc = loop_finish(ls[r], !small))) return rc;
         HIPCHK(hipEventRecord(ls[r]->ev_total[1], ls[r]->stream));
     }
     for (int r = 0; r < n; ++r) HIPCHK(hipStreamSynchronize(ls[r]->stream));
+    if (small && ls[0]->kfinal_host[1] != 0) {       // a barrier spin gave up (grid not resident?): repeat with one launch per body
+        ls[0]->small_disabled = true;
+        return run_loops(ls, n, k_out);
+    }
     for (int r = 0; r < n; ++r) {
         float k = 0.f;
         if ((rc = loop_collect(ls[r], &k))) return rc;

@@ -45,6 +45,18 @@ struct GnnFusedArgs {
     unsigned long long *stamps;
 };
 
+// control block of the persistent small-graph loop (gnn_small.hip)
+struct GnnSmallCtl {
+    float *state0, *state1;  // the two state replicas (ping-pong), all rows
+    const float *init;       // initial state of the owned rows [n_rows, Ds] (injected / drawn state, or the node labels for D == 0)
+    int *kfinal;             // receives the number of executed bodies
+    int *flags;              // word [b * GNN_FLAG_WORDS]: barrier + gate of body b (low half arrivals, high half movers), zeroed before
+    int *status;             // set to 1 by the kernel when a barrier spin gave up
+    int max_iter;
+};
+bool gnn_small_launch(int layers, int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
+                      hipStream_t st);
+
 // one per translation unit gnn_fused_l{1,2,3}.hip; false = no instantiation for (act, nt, ntl)
 bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 // split-arithmetic instantiations: gnn_fused_s{1,2,3}.hip

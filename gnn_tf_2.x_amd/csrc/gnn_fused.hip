@@ -215,22 +215,21 @@ int gnn_fused_prepare(gnn_loop *l)
     return GNN_OK;
 }
 
-int gnn_fused_iteration(gnn_loop *l, int k)
+// everything of the kernel arguments that does not depend on the launch geometry; split: arithmetic mode / tile layout
+static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs &a)
 {
     const gnn_graph *g = l->g;
     const gnn_mlp *m = l->st;
-    FusedPlan p;
     if (!make_plan(m, l->NLc, p)) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused path does not cover this net_state");
     if (m->pack_nlc != l->NLc) return gnn_fail(GNN_ERR_STATE, "weight image laid out for another label width");
     const int cur = k & 1, nxt = cur ^ 1, P = l->world;
-    GnnFusedArgs a{};
+    a = GnnFusedArgs{};
     a.n_rows = g->n_rows; a.row_begin = l->own_off;     // replica row of the first owned row
     a.indptr = g->sh->indptr; a.adj_src = g->sh->adj_src; a.adj_w = g->sh->adj_w;
     a.inv = l->inv;
     a.state_cur = l->state[cur];
     a.state_bytes = (int64_t)l->N_pad * l->Ds * (int64_t)sizeof(float);
     a.state_nxt = l->state[nxt] + (size_t)l->own_off * l->Ds;
-    const bool split = l->impl_req == 2;
     const int pad = split ? p.pad : 0;
     a.Ds = l->Ds; a.NLc = l->NLc; a.AL = g->AL; a.IW = 2 * l->NLc + g->AL; a.in_s = l->in_s + pad; a.c_aggs = l->Ds + l->NLc + pad;
     a.KP = split ? p.KPs : p.KP; a.kk0 = p.kk0;
@@ -256,6 +255,17 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     a.world = P;
     a.stamps = nullptr;
     a.wstride = 1;
+    return GNN_OK;
+}
+
+int gnn_fused_iteration(gnn_loop *l, int k)
+{
+    const gnn_graph *g = l->g;
+    FusedPlan p;
+    GnnFusedArgs a;
+    const bool split = l->impl_req == 2;
+    int rc = fused_args(l, k, split, p, a);
+    if (rc) return rc;
     const size_t n_tiles = (size_t)((g->n_rows + 31) / 32);
 #ifdef GNN_DIAG
     static const int variant_env = getenv("GNN_FUSED_VARIANT") ? atoi(getenv("GNN_FUSED_VARIANT")) : GNN_FUSED_VARIANT_DEFAULT;
@@ -310,5 +320,47 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     }
 #endif
     HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// persistent small-graph loop (device code: gnn_small.hip)
+// ---------------------------------------------------------------------------------------------------------------------
+bool gnn_small_supported(const gnn_loop *l)
+{
+    if (l->world != 1 || l->impl_req < 1 || l->small_disabled || l->profiling) return false;
+    if (!gnn_fused_supported(l)) return false;
+    FusedPlan p;
+    if (!make_plan(l->st, l->NLc, p)) return false;
+    if (p.NT != 1 || p.NTL != 1) return false;                      // nets no wider than 32 (one 32-feature tile per layer)
+    const int64_t n_tiles = (l->g->n_rows + 31) / 32;
+    if (p.kk0 > 48) return false;                                   // layer-0 weights are kept in registers
+    return n_tiles >= 1 && n_tiles <= 256;                          // every tile resident at once (one wave each), with a wide margin
+}
+
+int gnn_small_run(gnn_loop *l)
+{
+    FusedPlan p;
+    GnnFusedArgs a;
+    int rc = fused_args(l, 0, false, p, a);                          // exact f32-MFMA arithmetic, unpadded tile layout
+    if (rc) return rc;
+    a.gate = nullptr; a.flag_out = nullptr; a.tile_ctr = nullptr; a.stagger = 0;
+    GnnSmallCtl c{};
+    c.state0 = l->state[0]; c.state1 = l->state[1];
+    c.init = l->D ? l->state_init : l->g->nodes + (size_t)l->g->own_off * l->g->NL;      // D == 0: NL == Ds (GNN.py:265)
+    c.kfinal = l->kfinal_dev;
+    c.flags = l->flags;
+    int *ctl = l->flags + (size_t)(l->max_iter + 2) * GNN_FLAG_WORDS;      // world == 1
+    c.status = ctl + 1;
+    c.max_iter = l->max_iter;
+    // one memset for everything the kernel polls: the gates and, behind them in the same allocation, barrier counter + status
+    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * ((size_t)(l->max_iter + 2) * GNN_FLAG_WORDS + 4), l->stream));
+    const unsigned grid = (unsigned)((l->g->n_rows + 31) / 32);
+    const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 96 + 4);
+    const int rnd = l->g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
+    if (!gnn_small_launch(p.layers, p.act, p.kk0, rnd, a, c, grid, lds, l->stream))
+        return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(l->kfinal_host + 1, ctl + 1, sizeof(int), hipMemcpyDeviceToHost, l->stream));
     return GNN_OK;
 }

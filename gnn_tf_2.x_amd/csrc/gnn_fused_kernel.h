@@ -47,6 +47,22 @@ __device__ __forceinline__ v2f gload2(const float *p) { return *(const GNN_GLOBA
 __device__ __forceinline__ float gload1(const float *p) { return *(const GNN_GLOBAL float *)p; }
 __device__ __forceinline__ int gload1(const int *p) { return *(const GNN_GLOBAL int *)p; }
 
+// State rows that ANOTHER workgroup of the same launch has written (the persistent small-graph loop, k_small_loop): loads and
+// stores that bypass this CU's L1 / write through the XCD's L2 (global_load / global_store ... sc1), the form under which the
+// hand-off needs no cache fences (cdna_hip_programming.md Guideline 16, R1; MI355X_MICROARCH.md hand-off table, row 1).
+template <bool COH>
+__device__ __forceinline__ float sload1(const float *p)
+{
+    if constexpr (COH) return __hip_atomic_load(const_cast<GNN_GLOBAL float *>((const GNN_GLOBAL float *)p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return gload1(p);
+}
+template <bool COH>
+__device__ __forceinline__ void sstore1(float *p, float v)
+{
+    if constexpr (COH) __hip_atomic_store((GNN_GLOBAL float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *(GNN_GLOBAL float *)p = v;
+}
+
 __device__ __forceinline__ float shfl_f(float v, int src_lane)
 {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -571,22 +587,34 @@ __device__ __forceinline__ void zero_pad_columns(const GnnFusedArgs &a, float *X
 }
 
 // Generic shapes (any Ds, partial tiles).  Correct for everything, tuned for nothing: small graphs are launch-bound.
+// COH: the state rows are read with L1-bypassing loads (see sload1).
+// own_from_lds (k_small_loop, bodies > 0): the tile is still in LDS from the previous body - zero padding and label columns are
+// unchanged, the new own state sits in columns c_aggs.. and only has to move to columns 0..
+// RND: entries per round of the narrow gather (ids / weights, then rows of RND entries requested together)
+template <bool COH = false, int RND = 4>
 __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
-                                               int nvalid, int KP, int c_aggs)
+                                               int nvalid, int KP, int c_aggs, bool own_from_lds = false)
 {
     const int Ds = a.Ds, NLc = a.NLc;
-    zero_pad_columns(a, X, lane, KP);
-    if (nvalid < 32) {
-        RowCol rc(lane, a.in_s);
-        for (int t = lane; t < (32 - nvalid) * a.in_s; t += 64, rc.next()) X[(nvalid + rc.i) * KP + rc.c] = 0.0f;
+    if (!own_from_lds) {
+        zero_pad_columns(a, X, lane, KP);
+        if (nvalid < 32) {
+            RowCol rc(lane, a.in_s);
+            for (int t = lane; t < (32 - nvalid) * a.in_s; t += 64, rc.next()) X[(nvalid + rc.i) * KP + rc.c] = 0.0f;
+        }
     }
-    {   // own state rows (contiguous in HBM) into columns [0, Ds)
+    if (own_from_lds) {
+        const int total = nvalid * Ds;
+        RowCol rc(lane, Ds);
+        for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + rc.c] = X[rc.i * KP + c_aggs + rc.c];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // before the aggregated state overwrites those columns
+    } else {   // own state rows (contiguous in HBM) into columns [0, Ds)
         const float *src = a.state_cur + (a.row_begin + i0) * Ds;
         const int total = nvalid * Ds;
         RowCol rc(lane, Ds);
-        for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + rc.c] = gload1(src + t);
+        for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + rc.c] = sload1<COH>(src + t);
     }
-    if (a.IW > 0) {
+    if (a.IW > 0 && !own_from_lds) {
         const float *src = a.inv + i0 * a.IW;
         const int total = nvalid * a.IW;
         RowCol rc(lane, a.IW);
@@ -602,24 +630,24 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
         float acc[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
-        // four entries per round: their ids / weights are requested together, then their rows, then the fmaf chain in stored
+        // RND entries per round: their ids / weights are requested together, then their rows, then the fmaf chain in stored
         // order - two memory latencies per round instead of two per entry
-        for (int e = beg; e < end; e += 4) {
-            float w[4];
-            const float *xp[4];
+        for (int e = beg; e < end; e += RND) {
+            float w[RND];
+            const float *xp[RND];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RND; ++u) {
                 const int ee = e + u < end ? e + u : e;        // clamp: a real entry, result unused
                 w[u] = gload1(a.adj_w + ee);
                 xp[u] = a.state_cur + (int64_t)gload1(a.adj_src + ee) * Ds + cbeg;
             }
-            float x[4][16];
+            float x[RND][16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < RND; ++u)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x[u][c] = (cbeg + c < cend) ? gload1(xp[u] + c) : 0.0f;
+                for (int c = 0; c < 16; ++c) x[u][c] = (cbeg + c < cend) ? sload1<COH>(xp[u] + c) : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < RND; ++u)
                 if (e + u < end) {
 #pragma unroll
                     for (int c = 0; c < 16; ++c)
@@ -650,8 +678,10 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
                 const int ee = e + u < end ? e + u : e;    // clamp: a real entry, result unused
                 w[u] = gload1(a.adj_w + ee);
                 const float *xp = a.state_cur + (int64_t)gload1(a.adj_src + ee) * Ds + c0;
-                if (a.vec == 4) x[u] = gload4(xp);
-                else x[u] = v4f{gload1(xp), 0.f, 0.f, 0.f};
+                if (a.vec == 4) {
+                    if constexpr (COH) x[u] = v4f{sload1<true>(xp), sload1<true>(xp + 1), sload1<true>(xp + 2), sload1<true>(xp + 3)};
+                    else x[u] = gload4(xp);
+                } else x[u] = v4f{sload1<COH>(xp), 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -794,8 +824,10 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
 
 // condition() for the next body + coalesced store of the new rows.  New state sits in columns [c_aggs, c_aggs + Ds).
 // lanes 0..31 sum (new - old)^2, lanes 32..63 sum old^2, ascending feature order, unfused (oracle order).
+// moved_out != nullptr: the verdict "some node of the tile still moves" is returned there instead of raised in a.flag_out
+template <bool COH = false>
 __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int nvalid, int KP,
-                                                 int c_aggs)
+                                                 int c_aggs, int *moved_out = nullptr)
 {
     const int Ds = a.Ds, half = lane >> 5;
     const float *xo = X + (lane & 31) * KP, *xn = xo + c_aggs;
@@ -810,11 +842,12 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
     const float nrm = shfl_f(root, (lane & 31) + 32);
     const float rhs = a.thr * nrm;
     const int moved = (half == 0) && ((lane & 31) < nvalid) && (root > rhs);
-    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    if (moved_out) *moved_out = __any(moved) ? 1 : 0;
+    else if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
     float *dst = a.state_nxt + i0 * Ds;
     const int total = nvalid * Ds;
     RowCol rc(lane, Ds);
-    for (int t = lane; t < total; t += 64, rc.next()) gptr_w(dst)[t] = X[rc.i * KP + c_aggs + rc.c];
+    for (int t = lane; t < total; t += 64, rc.next()) sstore1<COH>(dst + t, X[rc.i * KP + c_aggs + rc.c]);
 }
 
 __device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int KP, int c_aggs)

@@ -190,6 +190,11 @@ int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets
  *       (tests: 1e-5 against the float64 oracle, the tolerance of BASELINE.json), not bit for bit.
  * 1 and 2 fall back to 0 when the shapes are not covered.  *used (may be NULL) reports the choice. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);
+/* Small graphs (every 32-node tile resident at once: <= 8,192 owned nodes, single GPU) with a net_state no wider than 32 run
+ * the whole tf.while_loop of GNN/GNN.py:271 - initial state, first condition, every body with a grid barrier in between - in
+ * ONE persistent launch when impl is 1 or 2 (exact f32-MFMA arithmetic in both cases, bit-identical to the oracle).  enable = 0
+ * keeps such a loop to one launch per body; *used (may be NULL) tells whether the persistent launch will be taken. */
+int gnn_loop_set_persistent(gnn_loop *l, int enable, int *used);
 /* per-kernel HIP-event timing of the last gnn_loop_run when profiling was enabled:
  * avg_iter_ms = mean duration of the per-iteration kernel(s), total_ms = whole loop on the stream. */
 int gnn_loop_set_profiling(gnn_loop *l, int enable);

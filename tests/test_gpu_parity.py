@@ -599,3 +599,33 @@ def test_wide_states_and_fallback(d, hidden, expect_fused):
     assert (loop.set_impl(2) == 2) == expect_fused
     k = loop.run()
     assert k == kc and np.max(np.abs(loop.state() - sc)) < 2e-6 * max(1.0, float(np.max(np.abs(sc))))
+
+
+@pytest.mark.parametrize('d,nl,al,hidden,act,n', [(0, 14, 3, (32, 32), 'selu', 970), (0, 3, 1, (), 'selu', 880), (8, 3, 2, (16,), 'tanh', 4099),
+                                                   (5, 2, 1, (7, 9), 'relu', 33), (16, 3, 1, (24,), 'sigmoid', 8192)])
+def test_persistent_small_graph_loop(d, nl, al, hidden, act, n):
+    """Small graphs run initial state, first condition and every body of the loop (GNN.py:266-271) inside ONE persistent launch
+    with a grid barrier between the bodies.  k, states and outputs: bit-identical to the C oracle and to one launch per body,
+    for both fused modes, over several thresholds (so that the loop leaves at different bodies) and on repeated runs."""
+    e = _engine()
+    rng = np.random.default_rng(7000 + n + d)
+    g, st, ou, s0 = _case(rng, n=n, d=d, nl=nl, al=al, hidden=hidden, act=act)
+    g['set_mask'] = rng.random(n) < 0.8
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    graph = _device_graph(g)
+    for thr, max_it in ((0.01, 30), (0.2, 30), (0.0, 7), (0.01, 0), (1e9, 5)):
+        kc, sc, oc = corc.loop_node(g, st, ou, d, max_it, thr, s0)
+        for impl in (1, 2):
+            loop = e.Loop(graph, mst, mou, d, max_it, thr)
+            loop.set_impl(impl)
+            assert loop.set_persistent(True)
+            if d: loop.set_state0(s0)
+            for _ in range(2):
+                k = loop.run()
+                assert k == kc and np.array_equal(loop.state(), sc) and np.array_equal(loop.output(), oc), (thr, max_it, impl)
+            assert not loop.set_persistent(False)
+            k = loop.run()                                   # one launch per body
+            if impl == 1: assert k == kc and np.array_equal(loop.state(), sc) and np.array_equal(loop.output(), oc)
+            loop.close()
+    big = e.Loop(_device_graph(_case(rng, n=8193, d=4)[0]), *[e.Mlp(x['weights'], x['activations'], True) for x in _case(np.random.default_rng(1), n=8193, d=4)[1:3]], 4, 5, 0.01)
+    assert not big.set_persistent(True)                   # 257 tiles: not all resident at once by the conservative rule
