@@ -1110,7 +1110,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
         if (!rc && hipMemset(l->state[b], 0, sizeof(float) * (size_t)l->N_pad * Ds) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "memset");
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS + 4);   // + barrier counter / status of the persistent loop
-    if (!rc) rc = dev_alloc(&l->kfinal_dev, 1);
+    if (!rc) rc = dev_alloc(&l->kfinal_dev, 2);        // k, status word of the persistent loop
     if (!rc) rc = dev_alloc(&l->tile_ctr, ((size_t)max_iter + 1 + 3) & ~(size_t)3);
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, 2 * sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc) l->kfinal_host[1] = 0;
@@ -1378,7 +1378,7 @@ static int loop_finish(gnn_loop *l, bool finalize)
         hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, l->world, l->max_iter, l->kfinal_dev);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, (finalize ? 1 : 2) * sizeof(int), hipMemcpyDeviceToHost, st));
     const float *own0 = l->state[0] + (size_t)l->own_off * l->Ds, *own1 = l->state[1] + (size_t)l->own_off * l->Ds;
     const float *nodes_own = g->nodes + (size_t)g->own_off * g->NL;
 

@@ -50,8 +50,8 @@ struct GnnSmallCtl {
     float *state0, *state1;  // the two state replicas (ping-pong), all rows
     const float *init;       // initial state of the owned rows [n_rows, Ds] (injected / drawn state, or the node labels for D == 0)
     int *kfinal;             // receives the number of executed bodies
-    int *flags;              // word [b * GNN_FLAG_WORDS]: barrier + gate of body b (low half arrivals, high half movers), zeroed before
-    int *status;             // set to 1 by the kernel when a barrier spin gave up
+    int *flags;              // word [b]: barrier + gate of body b (low half arrivals, high half movers), zeroed before the launch
+    int *status;             // = kfinal + 1: set to 1 by a workgroup whose barrier spin gave up, to 0 at the regular end
     int max_iter;
 };
 bool gnn_small_launch(int layers, int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,

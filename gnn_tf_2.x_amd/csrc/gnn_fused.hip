@@ -350,17 +350,15 @@ int gnn_small_run(gnn_loop *l)
     c.init = l->D ? l->state_init : l->g->nodes + (size_t)l->g->own_off * l->g->NL;      // D == 0: NL == Ds (GNN.py:265)
     c.kfinal = l->kfinal_dev;
     c.flags = l->flags;
-    int *ctl = l->flags + (size_t)(l->max_iter + 2) * GNN_FLAG_WORDS;      // world == 1
-    c.status = ctl + 1;
+    c.status = l->kfinal_dev + 1;
     c.max_iter = l->max_iter;
-    // one memset for everything the kernel polls: the gates and, behind them in the same allocation, barrier counter + status
-    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * ((size_t)(l->max_iter + 2) * GNN_FLAG_WORDS + 4), l->stream));
+    // the only words the kernel polls: one per body at the start of the flag block, zeroed as one 16-byte-multiple block
+    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (((size_t)l->max_iter + 2 + 3) & ~(size_t)3), l->stream));
     const unsigned grid = (unsigned)((l->g->n_rows + 31) / 32);
     const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 96 + 4);
     const int rnd = l->g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
     if (!gnn_small_launch(p.layers, p.act, p.kk0, rnd, a, c, grid, lds, l->stream))
         return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(l->kfinal_host + 1, ctl + 1, sizeof(int), hipMemcpyDeviceToHost, l->stream));
-    return GNN_OK;
+    return GNN_OK;      // k and the status word travel in ONE 8-byte copy (loop_finish)
 }

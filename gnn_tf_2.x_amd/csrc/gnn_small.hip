@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned seen = 0;
         if (lane == 0) {
-            GNN_GLOBAL unsigned *word = (GNN_GLOBAL unsigned *)(c.flags + (size_t)b * GNN_FLAG_WORDS);
+            GNN_GLOBAL unsigned *word = (GNN_GLOBAL unsigned *)(c.flags + b);
             __hip_atomic_fetch_add(word, 1u + (moved ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (unsigned spins = 0;; ++spins) {
                 seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         go = arrive_and_gate(k + 1, moved);
     }
     if (go < 0) return;
-    if (blockIdx.x == 0 && lane == 0) *c.kfinal = k;                  // executed bodies (GNN.py:267): every workgroup agrees on it
+    if (blockIdx.x == 0 && lane == 0) { c.kfinal[0] = k; c.kfinal[1] = 0; }   // executed bodies (GNN.py:267; every workgroup agrees), status ok
 }
 
 template <int LAYERS, int ACT>
