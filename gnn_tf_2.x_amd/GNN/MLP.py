@@ -174,7 +174,7 @@ class Sequential:
             if isinstance(layer, Dense):
                 idx += 1
             elif isinstance(layer, AlphaDropout):
-                raise NotImplementedError('AlphaDropout in training mode is not implemented on the MI355X engine')
+                rates[idx] = -float(layer.rate)          # the engine's code for AlphaDropout (include/gnn_hip.h)
             elif isinstance(layer, Dropout):
                 rates[idx] = float(layer.rate)
         return rates

@@ -30,11 +30,10 @@ mse = mean_squared_error
 
 
 def device_loss_kind(fn, loss_args) -> int:
-    """Loss code of gnn_loop_train_step for the callables above (0 categorical_crossentropy, 1 mean_squared_error)."""
+    """Loss code of gnn_loop_train_step for the callables above (0 categorical_crossentropy, 1 mean_squared_error,
+    2 categorical_crossentropy(from_logits=True))."""
     if fn is categorical_crossentropy:
-        if loss_args.get('from_logits', False):
-            raise NotImplementedError('categorical_crossentropy(from_logits=True) is not implemented for training on the device')
-        return 0
+        return 2 if loss_args.get('from_logits', False) else 0
     if fn is mean_squared_error:
         return 1
     raise NotImplementedError(f'training with loss {getattr(fn, "__name__", fn)!r} is not implemented on the MI355X engine '

@@ -4,7 +4,7 @@
 // gradients and the BatchNormalization batch statistics of every executed body.
 //
 // Keras training semantics (not in the reference repository; restated in oracle/gnn_train_oracle.py):
-//   Dropout: y = x * mask / (1 - rate), fresh mask per call;  BatchNormalization: batch mean / biased batch variance;
+//   Dropout: y = x * mask / (1 - rate), fresh mask per call (negative rate: AlphaDropout);  BatchNormalization: batch mean / biased batch variance;
 //   categorical_crossentropy(from_logits=False): p = out / sum(out), clip to [1e-7, 1 - 1e-7], -sum t log p.
 // This path is built from simple per-op kernels (correctness first; training graphs are small batches); float32 with
 // atomically accumulated weight gradients, so it is compared with the oracle to a tolerance, not bit for bit.
@@ -25,7 +25,9 @@ inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b);
 inline int64_t rows_per_block(int64_t n)
 {
     const int64_t r = ((n + 63) / 64 + 15) / 16 * 16;
-    return std::min<int64_t>(1024, std::max<int64_t>(32, r));
+    const int64_t capped = std::min<int64_t>(1024, std::max<int64_t>(32, r));
+    // at most 256 row chunks: every chunk leaves a partial result that a second pass adds up in chunk order
+    return std::max<int64_t>(capped, ((n + 255) / 256 + 15) / 16 * 16);
 }
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
@@ -36,22 +38,44 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x ^ (x >> 31);
 }
 
+// AlphaDropout (Keras; reference GNN/MLP.py:59-61 with alphadropout=True) is passed as a NEGATIVE rate: dropped units are set to
+// alpha' = -selu_scale * selu_alpha and the result is mapped by a x + b so that mean and variance of selu activations are kept:
+//   a = ((1 - r)(1 + r alpha'^2))^-1/2,  b = -a alpha' r,  y = a (x keep + alpha' (1 - keep)) + b,  dy/dx = a keep
+__device__ __forceinline__ void alpha_dropout_coeffs(float r, float *a, float *b, float *alpha_p)
+{
+    const float ap = -1.0507009873554805f * 1.6732632423543772f;
+    const float aa = 1.0f / sqrtf((1.0f - r) * (1.0f + r * ap * ap));
+    *a = aa; *b = -aa * ap * r; *alpha_p = ap;
+}
+
 // Dropout forward: keep[i] = injected mask or own RNG; y = x * keep / (1 - rate); keep bytes are stored for the backward pass
 __global__ void k_dropout_fwd(int64_t n, const float *x, const uint8_t *mask_in, float rate, uint64_t seed, uint8_t *keep, float *y)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const float r = fabsf(rate);
     uint8_t kp;
     if (mask_in) kp = mask_in[i] != 0;
-    else kp = ((mix64(seed ^ mix64((uint64_t)i)) >> 40) * (1.0f / 16777216.0f)) >= rate;
+    else kp = ((mix64(seed ^ mix64((uint64_t)i)) >> 40) * (1.0f / 16777216.0f)) >= r;
     keep[i] = kp;
-    y[i] = kp ? x[i] / (1.0f - rate) : 0.0f;
+    if (rate < 0.0f) {
+        float a, b, ap;
+        alpha_dropout_coeffs(r, &a, &b, &ap);
+        y[i] = a * (kp ? x[i] : ap) + b;
+    } else
+        y[i] = kp ? x[i] / (1.0f - rate) : 0.0f;
 }
 
 __global__ void k_dropout_bwd(int64_t n, const uint8_t *keep, float rate, float *d)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) d[i] = keep[i] ? d[i] / (1.0f - rate) : 0.0f;
+    if (i >= n) return;
+    if (rate < 0.0f) {
+        float a, b, ap;
+        alpha_dropout_coeffs(-rate, &a, &b, &ap);
+        d[i] = keep[i] ? d[i] * a : 0.0f;
+    } else
+        d[i] = keep[i] ? d[i] / (1.0f - rate) : 0.0f;
 }
 
 __global__ void k_act_fwd(int64_t n, int F, const float *z, int act, float *a)
@@ -120,9 +144,20 @@ __global__ void k_colreduce(int64_t n, int F, const float *x, const float *y, co
     __syncthreads();
     if (ry == 0 && j < F) {
         for (int t = 1; t < 8; ++t) { a0 += s0[t][c]; a1 += s1[t][c]; }
-        atomicAdd(out0 + j, a0);
-        if (mode == 2) atomicAdd(out1 + j, a1);
+        // partial of this row chunk; k_sum_parts adds the chunks in a fixed order (run-to-run identical sums, no float atomics)
+        out0[(size_t)blockIdx.y * F + j] = a0;
+        if (mode == 2) out1[(size_t)blockIdx.y * F + j] = a1;
     }
+}
+
+// out[t] += part[0][t] + part[1][t] + ... (ascending chunk index), t < count
+__global__ void k_sum_parts(int parts, int64_t count, const float *part, float *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    float acc = 0.0f;
+    for (int z = 0; z < parts; ++z) acc += part[(size_t)z * count + t];
+    out[t] += acc;
 }
 
 __global__ void k_scale_vec(int n, float *v, float s)
@@ -172,7 +207,7 @@ __global__ void k_wgrad(int64_t n, int n_in, int n_out, const float *H, const fl
         for (int q = 0; q < 16; ++q) acc += sh[q][ti] * sz[q][tj];
         __syncthreads();
     }
-    if (i0 + ti < n_in && j0 + tj < n_out) atomicAdd(dW + (size_t)(i0 + ti) * n_out + j0 + tj, acc);
+    if (i0 + ti < n_in && j0 + tj < n_out) dW[(size_t)blockIdx.z * n_in * n_out + (size_t)(i0 + ti) * n_out + j0 + tj] = acc;   // partial of chunk z
 }
 
 __global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
@@ -242,6 +277,38 @@ struct Buf {                      // typed front end of the arena
         return GNN_OK;
     }
 };
+
+// out0[j] (+ out1[j]) += column reduction of k_colreduce over all n rows, deterministic: partials per row chunk, then k_sum_parts
+static int reduce_cols(hipStream_t st, Buf &buf, int64_t n, int F, const float *x, const float *y, const float *aux0, int mode, float *out0, float *out1)
+{
+    if (n <= 0 || F <= 0) return GNN_OK;
+    const int64_t rpb = rows_per_block(n);
+    const int parts = (int)cdiv(n, rpb);
+    float *p0 = nullptr, *p1 = nullptr;
+    int rc = buf.get(&p0, (size_t)parts * F);
+    if (!rc && mode == 2) rc = buf.get(&p1, (size_t)parts * F);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_colreduce, dim3(cdiv(F, 32), parts), 256, 0, st, n, F, x, y, aux0, mode, p0, p1, rpb);
+    hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, parts, (int64_t)F, p0, out0);
+    if (mode == 2) hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, parts, (int64_t)F, p1, out1);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
+// dW += H^T . DZ, deterministic in the same way
+static int weight_grad(hipStream_t st, Buf &buf, int64_t n, int ni, int no, const float *H, const float *DZ, float *dW)
+{
+    if (n <= 0) return GNN_OK;
+    const int64_t rpb = rows_per_block(n);
+    const int parts = (int)cdiv(n, rpb);
+    float *part = nullptr;
+    int rc = buf.get(&part, (size_t)parts * ni * no);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_wgrad, dim3(cdiv(ni, 16), cdiv(no, 16), parts), 256, 0, st, n, ni, no, H, DZ, part, rpb);
+    hipLaunchKernelGGL(k_sum_parts, cdiv((int64_t)ni * no, 256), 256, 0, st, parts, (int64_t)ni * no, part, dW);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
 
 __global__ void k_transpose(int ni, int no, const float *W, float *WT)
 {
@@ -316,7 +383,7 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
     int rc;
     for (int l = 0; l <= L; ++l) {
         const int width = m->dims[l];
-        if (net.rate[l] > 0.0f) {
+        if (net.rate[l] != 0.0f) {
             float *hd = nullptr;
             if ((rc = buf.get(&hd, (size_t)n * width)) || (rc = buf.get(&c.keep[l], (size_t)n * width))) return rc;
             if (n > 0) {
@@ -347,11 +414,9 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
         HIPCHK(hipMemsetAsync(sums, 0, sizeof(float) * 2 * F, st));
         HIPCHK(hipMemsetAsync(c.stats, 0, sizeof(float) * 2 * F, st));
         if (n > 0) {
-            const int64_t rpb = rows_per_block(n);
-            dim3 grid(cdiv(F, 32), cdiv(n, rpb));
-            hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, h, (const float *)nullptr, (const float *)nullptr, 0, sums, (float *)nullptr, rpb);
+            if ((rc = reduce_cols(st, buf, n, F, h, nullptr, nullptr, 0, sums, nullptr))) return rc;
             hipLaunchKernelGGL(k_scale_vec, cdiv(F, 64), 64, 0, st, F, sums, 1.0f / (float)n);                       // sums -> batch mean
-            hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, h, (const float *)nullptr, sums, 1, sums + F, (float *)nullptr, rpb);
+            if ((rc = reduce_cols(st, buf, n, F, h, nullptr, sums, 1, sums + F, nullptr))) return rc;
             hipLaunchKernelGGL(k_bn_fwd, cdiv(n * F, 256), 256, 0, st, n, F, h, sums, sums + F, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
         }
@@ -369,22 +434,20 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
     const int L = m->n_layers;
     const int64_t n = c.n;
     int rc;
-    const int64_t rpb = rows_per_block(n);
     if (m->has_bn && n > 0) {
         const int F = m->dims.back();
         float *dgamma = net.grads + net.g_off[2 * L], *dbeta = net.grads + net.g_off[2 * L + 1];
         float *loc = nullptr;                      // this call's own column sums (the grads accumulate over iterations)
         if ((rc = buf.get(&loc, (size_t)2 * F))) return rc;
         HIPCHK(hipMemsetAsync(loc, 0, sizeof(float) * 2 * F, st));
-        dim3 grid(cdiv(F, 32), cdiv(n, rpb));
-        hipLaunchKernelGGL(k_colreduce, grid, 256, 0, st, n, F, d, c.xhat, (const float *)nullptr, 2, loc, loc + F, rpb);
+        if ((rc = reduce_cols(st, buf, n, F, d, c.xhat, nullptr, 2, loc, loc + F))) return rc;
         hipLaunchKernelGGL(k_bn_bwd, cdiv(n * F, 256), 256, 0, st, n, F, d, c.xhat, net.gamma, c.stats, m->eps, loc, loc + F);
         // dgamma += loc[0:F], dbeta += loc[F:2F]
-        hipLaunchKernelGGL(k_colreduce, dim3(cdiv(F, 32), 1), 256, 0, st, 1, F, loc, (const float *)nullptr, (const float *)nullptr, 0, dgamma, (float *)nullptr, (int64_t)1);
-        hipLaunchKernelGGL(k_colreduce, dim3(cdiv(F, 32), 1), 256, 0, st, 1, F, loc + F, (const float *)nullptr, (const float *)nullptr, 0, dbeta, (float *)nullptr, (int64_t)1);
+        hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, 1, (int64_t)F, loc, dgamma);
+        hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, 1, (int64_t)F, loc + F, dbeta);
         HIPCHK(hipGetLastError());
     }
-    if (net.rate[L] > 0.0f && n > 0) {
+    if (net.rate[L] != 0.0f && n > 0) {
         const int F = m->dims.back();
         hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * F, 256), 256, 0, st, n * F, c.keep[L], net.rate[L], d);
         HIPCHK(hipGetLastError());
@@ -396,15 +459,13 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         if (n > 0) {
             const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;
             hipLaunchKernelGGL(k_act_bwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, d, c.a[l], m->acts[l]);
-            dim3 gw(cdiv(ni, 16), cdiv(no, 16), cdiv(n, rpb));
-            hipLaunchKernelGGL(k_wgrad, gw, 256, 0, st, n, ni, no, c.hin[l], d, net.grads + net.g_off[2 * l], rpb);
-            dim3 gb(cdiv(no, 32), cdiv(n, rpb));
-            hipLaunchKernelGGL(k_colreduce, gb, 256, 0, st, n, no, d, (const float *)nullptr, (const float *)nullptr, 0, net.grads + net.g_off[2 * l + 1], (float *)nullptr, rpb);
             HIPCHK(hipGetLastError());
+            if ((rc = weight_grad(st, buf, n, ni, no, c.hin[l], d, net.grads + net.g_off[2 * l]))) return rc;
+            if ((rc = reduce_cols(st, buf, n, no, d, nullptr, nullptr, 0, net.grads + net.g_off[2 * l + 1], nullptr))) return rc;
         }
         // d h_in = d z . W^T  (bias-free: the zero vector behind the gradients)
         if ((rc = gnn_launch_dense(st, n, no, ni, d, no, net.WT[l], net.zero, GNN_ACT_LINEAR, dprev, ni))) return rc;
-        if (net.rate[l] > 0.0f && n > 0) {
+        if (net.rate[l] != 0.0f && n > 0) {
             hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * ni, 256), 256, 0, st, n * ni, c.keep[l], net.rate[l], dprev);
             HIPCHK(hipGetLastError());
         }
@@ -435,6 +496,16 @@ void loss_host(int kind, int64_t n, int T, const float *t, const float *o, const
                 gp += g[j] * p[j];
             }
             for (int j = 0; j < T; ++j) d_o[i * T + j] = (float)(w[i] * (g[j] - gp) / s);
+            total += w[i] * li;
+        } else if (kind == 2) {                    // categorical_crossentropy, from_logits=True: softmax inside the loss, no clipping
+            double mx = oi[0], s = 0.0, st = 0.0, li = 0.0;
+            for (int j = 1; j < T; ++j) mx = std::max(mx, (double)oi[j]);
+            for (int j = 0; j < T; ++j) { s += exp(oi[j] - mx); st += ti[j]; }
+            for (int j = 0; j < T; ++j) {
+                const double logp = (oi[j] - mx) - log(s);
+                li -= ti[j] * logp;
+                d_o[i * T + j] = (float)(w[i] * (exp(logp) * st - ti[j]));
+            }
             total += w[i] * li;
         } else {                                   // mean_squared_error
             double li = 0.0;
@@ -552,7 +623,7 @@ extern "C" int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const flo
                              double *loss, float *d_out)
 {
     ARGCHK((n_rows == 0 || (targets && out && sample_weights)) && loss && n_out > 0 && n_rows >= 0, "bad arguments");
-    ARGCHK(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error");
+    ARGCHK(loss_kind >= 0 && loss_kind <= 2, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error, 2 categorical_crossentropy(from_logits=True)");
     std::vector<float> d;
     loss_host(loss_kind, n_rows, n_out, targets, out, sample_weights, loss, d);
     if (d_out && n_rows) memcpy(d_out, d.data(), sizeof(float) * d.size());
@@ -642,9 +713,9 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     };
     // masks of one iteration of net_state: sum over the dropout positions of N * width bytes
     size_t mask_iter_bytes = 0;
-    for (int i = 0; i <= l->st->n_layers; ++i) if (dropout_state[i] > 0.0f) mask_iter_bytes += (size_t)N * l->st->dims[i];
+    for (int i = 0; i <= l->st->n_layers; ++i) if (dropout_state[i] != 0.0f) mask_iter_bytes += (size_t)N * l->st->dims[i];
     size_t mask_out_bytes = 0;
-    for (int i = 0; i <= l->ou->n_layers; ++i) if (dropout_output[i] > 0.0f) mask_out_bytes += (size_t)M * l->ou->dims[i];
+    for (int i = 0; i <= l->ou->n_layers; ++i) if (dropout_output[i] != 0.0f) mask_out_bytes += (size_t)M * l->ou->dims[i];
     uint8_t *d_masks_s = nullptr, *d_masks_o = nullptr;
     if (masks_state && mask_iter_bytes) {
         if ((rc = buf.get(&d_masks_s, mask_iter_bytes * (size_t)l->max_iter))) return rc;
@@ -808,7 +879,7 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
                                    float *bn_batch_state, float *bn_batch_output)
 {
     ARGCHK(l && targets && sample_weights && loss_out && k_out && grads_state && grads_output, "bad arguments");
-    ARGCHK(loss_kind == 0 || loss_kind == 1, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error");
+    ARGCHK(loss_kind >= 0 && loss_kind <= 2, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error, 2 categorical_crossentropy(from_logits=True)");
     const int64_t M = l->edge_mode ? l->n_edge_masked : l->g->n_masked;
     const int T = l->T;
     ARGCHK(!(l->edge_mode && n_graphs > 0), "an edge-based loop has no graph readout");

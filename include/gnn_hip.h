@@ -142,10 +142,11 @@ int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, const float
  *   src_*            Adjacency in CSR form BY SOURCE (rows = source node, inner = destination ascending): the transposed
  *                    aggregation of the backward pass; all NULL = derived from the graph's own CSR on first use and kept
  *   targets, sample_weights, n_targets   rows = masked nodes (node-based) or graphs (graph-based); loss_kind 0 =
- *                    categorical_crossentropy(from_logits=False), 1 = mean_squared_error
+ *                    categorical_crossentropy(from_logits=False), 1 = mean_squared_error, 2 = categorical_crossentropy(from_logits=True)
  *   n_graphs, ng_*   NodeGraph^T in CSR form (as gnn_loop_readout) for GNNgraphBased, n_graphs = 0 otherwise
  *   dropout_state / dropout_output   [n_layers + 1] Dropout rate in front of Dense l (0 = none; last entry: in front of
- *                    BatchNormalization), i.e. GNN/MLP.py:54-55 after its position shift
+ *                    BatchNormalization), i.e. GNN/MLP.py:54-55 after its position shift; a NEGATIVE value -r is an AlphaDropout
+ *                    of rate r (MLP(..., alphadropout=True), GNN/MLP.py:59-61)
  *   masks_*          injected keep-masks (uint8, 1 = keep): for net_state max_iter blocks, each the concatenation over the
  *                    dropout positions of [N, width]; for net_output one such block over the masked rows; NULL = engine RNG(seed)
  *   bn_state / bn_output   [gamma | beta] of the trailing BatchNormalization (NULL without one)

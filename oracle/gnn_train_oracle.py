@@ -59,7 +59,15 @@ def mlp_train_forward(x, net, masks, dtype=np.float64):
     cache = dict(h_in=[], z=[], a=[], scale={})
     for l in range(n):
         rate = net.get('dropout', {}).get(l)
-        if rate:
+        if rate and net.get('alphadropout'):
+            # Keras AlphaDropout (MLP.py:59-61 with alphadropout=True): dropped units -> alpha' = -scale * alpha, then a x + b
+            alpha_p = dtype(-1.0507009873554805 * 1.6732632423543772)
+            a_ = dtype(1) / np.sqrt(dtype(1 - rate) * (dtype(1) + dtype(rate) * alpha_p ** 2))
+            b_ = -a_ * alpha_p * dtype(rate)
+            keep = np.asarray(masks[l], dtype)
+            cache['scale'][l] = a_ * keep
+            h = a_ * (h * keep + alpha_p * (dtype(1) - keep)) + b_
+        elif rate:
             sc = np.asarray(masks[l], dtype) / dtype(1 - rate)
             cache['scale'][l] = sc
             h = h * sc
@@ -112,6 +120,11 @@ def loss_forward_backward(kind, targets, out, weights, dtype=np.float64):
         loss = -(t * np.log(pc)).sum(axis=-1)
         g = np.where((p >= EPS_K) & (p <= 1 - EPS_K), -t / pc, dtype(0))          # dL/dp (zero where clipped)
         do = (g - np.sum(g * p, axis=-1, keepdims=True)) / s
+    elif kind == 'categorical_crossentropy_from_logits':
+        z = o - o.max(axis=-1, keepdims=True)
+        logp = z - np.log(np.exp(z).sum(axis=-1, keepdims=True))
+        loss = -(t * logp).sum(axis=-1)
+        do = np.exp(logp) * t.sum(axis=-1, keepdims=True) - t
     elif kind == 'mean_squared_error':
         loss = ((o - t) ** 2).mean(axis=-1)
         do = dtype(2) * (o - t) / o.shape[-1]

@@ -20,9 +20,11 @@ def _by_source_csr(g, n):
     return sip, dst[order].astype(np.int32), np.asarray(w, np.float32)[order]
 
 
-@pytest.mark.parametrize('d,graph_based,act,loss', [(8, False, 'tanh', 'categorical_crossentropy'), (0, False, 'selu', 'categorical_crossentropy'),
-                                                      (5, True, 'sigmoid', 'mean_squared_error'), (0, True, 'relu', 'categorical_crossentropy')])
-def test_train_step_matches_oracle(d, graph_based, act, loss):
+@pytest.mark.parametrize('d,graph_based,act,loss,alpha', [(8, False, 'tanh', 'categorical_crossentropy', False), (0, False, 'selu', 'categorical_crossentropy', False),
+                                                            (5, True, 'sigmoid', 'mean_squared_error', False), (0, True, 'relu', 'categorical_crossentropy', False),
+                                                            (8, False, 'selu', 'categorical_crossentropy_from_logits', True)])
+def test_train_step_matches_oracle(d, graph_based, act, loss, alpha):
+    """alpha: AlphaDropout (negative rates on the C ABI); *_from_logits: loss_kind 2."""
     from GNN import _engine as e
     rng = np.random.default_rng(100 + d)
     n, nl, al, max_it = 500, 3, 2, 6
@@ -38,6 +40,9 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
     st = make_mlp(rng, al + 2 * (ds + nlc), [16, ds], act, gain=0.8, bn_random=True)
     ou = make_mlp(rng, ds + nlc, [9, 2], act, out_activation='softmax', bn_random=True)
     st['dropout'], ou['dropout'] = {0: 0.2}, {0: 0.1, 1: 0.3}
+    if alpha: st['alphadropout'] = ou['alphadropout'] = True
+    sgn = -1.0 if alpha else 1.0
+    kind = {'categorical_crossentropy': 0, 'mean_squared_error': 1, 'categorical_crossentropy_from_logits': 2}[loss]
     mask = g['set_mask'] & g['output_mask']
     m = int(mask.sum())
     in_s = st['weights'][0].shape[0]
@@ -65,8 +70,8 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
         cols, rows = np.nonzero(ng.T)
         ip = np.zeros(4, np.int32); np.cumsum(np.bincount(cols, minlength=3), out=ip[1:])
         ng_csr = (ip, rows.astype(np.int32), ng[rows, cols])
-    res = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0 if loss == 'categorical_crossentropy' else 1, ng_csr,
-                          dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], masks_state=ms, masks_output=mo,
+    res = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, kind, ng_csr,
+                          dropout_state=[sgn * 0.2, 0, 0], dropout_output=[sgn * 0.1, sgn * 0.3, 0], masks_state=ms, masks_output=mo,
                           bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]))
     assert res['k'] == ref['k'] and 1 <= res['k'] <= max_it
     assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
@@ -82,9 +87,17 @@ def test_train_step_matches_oracle(d, graph_based, act, loss):
     np.testing.assert_allclose(mov[0], ref['moving_state'][0], atol=1e-5)
     np.testing.assert_allclose(mov[1], ref['moving_state'][1], atol=1e-5)
     np.testing.assert_allclose(np.asarray(ou['weights'][-2], np.float64) * 0.99 + res['bn_batch_output'][0] * 0.01, ref['moving_output'][0], atol=1e-5)
+    # run-to-run determinism: the column reductions and weight gradients add per-chunk partials in a fixed order (no float atomics)
+    again = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, kind, ng_csr,
+                            dropout_state=[sgn * 0.2, 0, 0], dropout_output=[sgn * 0.1, sgn * 0.3, 0], masks_state=ms, masks_output=mo,
+                            bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]))
+    assert again['loss'] == res['loss'] and again['k'] == res['k']
+    for a_, b_ in zip(again['grads_state'] + again['grads_output'], res['grads_state'] + res['grads_output']):
+        assert np.array_equal(a_, b_)
+    assert np.array_equal(again['bn_batch_state'], res['bn_batch_state']) and np.array_equal(again['bn_batch_output'], res['bn_batch_output'])
     # engine RNG masks: same call without injected masks must run and give finite numbers with about the right keep rate
-    res2 = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0 if loss == 'categorical_crossentropy' else 1, ng_csr,
-                           dropout_state=[0.2, 0, 0], dropout_output=[0.1, 0.3, 0], seed=5,
+    res2 = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, kind, ng_csr,
+                           dropout_state=[sgn * 0.2, 0, 0], dropout_output=[sgn * 0.1, sgn * 0.3, 0], seed=5,
                            bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=np.concatenate(ou['weights'][-4:-2]))
     assert np.isfinite(res2['loss']) and all(np.isfinite(a).all() for a in res2['grads_state'] + res2['grads_output'])
 

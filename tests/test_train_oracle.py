@@ -32,11 +32,15 @@ def _case(rng, d, graph_based=False, act='tanh'):
     return g, st, ou, s0, masks_s, masks_o, targets, weights
 
 
-@pytest.mark.parametrize('d,graph_based,act,loss', [(4, False, 'tanh', 'categorical_crossentropy'), (0, False, 'selu', 'categorical_crossentropy'),
-                                                      (3, True, 'sigmoid', 'mean_squared_error'), (0, True, 'relu', 'categorical_crossentropy')])
-def test_gradients_match_finite_differences(d, graph_based, act, loss):
+@pytest.mark.parametrize('d,graph_based,act,loss,alpha', [(4, False, 'tanh', 'categorical_crossentropy', False), (0, False, 'selu', 'categorical_crossentropy', False),
+                                                            (3, True, 'sigmoid', 'mean_squared_error', False), (0, True, 'relu', 'categorical_crossentropy', False),
+                                                            (4, False, 'selu', 'categorical_crossentropy_from_logits', True)])
+def test_gradients_match_finite_differences(d, graph_based, act, loss, alpha):
+    """alpha: AlphaDropout in place of Dropout (MLP(..., alphadropout=True), reference MLP.py:59-61); *_from_logits: the loss of
+    starter.py:83 with from_logits=True."""
     rng = np.random.default_rng(3 + d)
     g, st, ou, s0, ms, mo, targets, weights = _case(rng, d, graph_based, act)
+    if alpha: st['alphadropout'] = ou['alphadropout'] = True
     # threshold 0 => exactly max_iteration bodies, so that the iteration count cannot flip under the perturbation
     kw = dict(state_vect_dim=d, max_iteration=4, threshold=0.0, state0=s0, masks_state=ms, masks_output=mo, targets=targets,
               sample_weights=weights, loss=loss, mean=False, graph_based=graph_based)
