@@ -51,7 +51,7 @@ dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows
 loops = [dur[i:i + 30] for i in range(0, len(dur) - len(dur) % 30, 30)]
 with open(f'profiles/{tag}_fused_kernel_per_loop.txt', 'w') as fo:
     fo.write(f'{k}\n{len(dur)} launches in the rocprofv3 kernel trace of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`, mean {sum(dur) / len(dur):.4f} ms\n')
-    names = ['warm-up Loop', 'timed step 1', 'timed step 2', 'PCIe-inclusive Loop']
+    names = ['warm-up Loop', 'timed step 1', 'timed step 2', 'exact-path comparison / cold-aggregates Loop', 'cold-aggregates Loop', 'PCIe-inclusive Loop']
     for i, l in enumerate(loops):
         fo.write(f'Loop {i} ({names[i] if i < len(names) else "extra"}): mean of its 30 launches {sum(l) / len(l):.4f} ms, min {min(l):.4f}, max {max(l):.4f}\n')
     fo.write(f'remaining launches (one-body comparison run): {[round(x, 4) for x in dur[len(loops) * 30:]]}\n')
