@@ -54,16 +54,45 @@ class GNNnodeBased(BaseClass):
                               path_writer=path_writer or self.path_writer + '_copied/', namespace=namespace or 'GNN')
 
     def save(self, path: str):
-        """net_state / net_output weights as .npz plus config.json (the reference writes Keras SavedModels, GNN.py:93-111)."""
+        """Save the model to folder <path>, without extra_metrics (reference GNN.py:93-111; the reference writes two Keras
+        SavedModels, here: architecture + weights of each net as JSON + .npz)."""
         import json, os
+        from GNN import losses, optimizers
+        from GNN.MLP import sequential_config
         if path[-1] != '/': path += '/'
         os.makedirs(path, exist_ok=True)
         for name, net in (('net_state', self.net_state), ('net_output', self.net_output)):
-            np.savez(f'{path}{name}.npz', *net.get_weights(), activations=np.array(net.activations, dtype=object),
-                     batch_normalization=net.batch_normalization)
+            np.savez(f'{path}{name}.npz', *net.get_weights())
+            with open(f'{path}{name}.json', 'w') as f:
+                json.dump(sequential_config(net), f)
+        loss_name = getattr(self.loss_function, '__name__', None)
         with open(f'{path}config.json', 'w') as f:
-            json.dump({'loss_arguments': self.loss_args, 'max_iteration': self.max_iteration, 'threshold': self.state_threshold,
+            json.dump({'loss_function': loss_name if hasattr(losses, str(loss_name)) else None, 'loss_arguments': self.loss_args,
+                       'optimizer': optimizers.serialize(self.optimizer), 'max_iteration': self.max_iteration, 'threshold': self.state_threshold,
                        'addressed_problem': self.addressed_problem, 'state_vect_dim': self.state_vect_dim}, f)
+
+    @classmethod
+    def load(cls, path: str, path_writer=None, namespace: str = 'GNN', extra_metrics=None, extra_metrics_arguments=None):
+        """Load a model saved by save() (reference GNN.py:114-149, same arguments): the GNN type is the calling class."""
+        import json
+        from GNN import losses, optimizers
+        from GNN.MLP import sequential_from_config
+        if path[-1] != '/': path += '/'
+        if path_writer is None: path_writer = f'{path}writer'
+        with open(f'{path}config.json') as f:
+            config = json.load(f)
+        optz = optimizers.deserialize(config.pop('optimizer', None))
+        loss_name = config.pop('loss_function', None)
+        loss = getattr(losses, loss_name) if loss_name else None
+        nets = []
+        for name in ('net_state', 'net_output'):
+            with open(f'{path}{name}.json') as f:
+                arch = json.load(f)
+            with np.load(f'{path}{name}.npz') as z:
+                weights = [z[f'arr_{i}'] for i in range(len(z.files))]
+            nets.append(sequential_from_config(arch, weights))
+        return cls(net_state=nets[0], net_output=nets[1], optimizer=optz, loss_function=loss, extra_metrics=extra_metrics,
+                   extra_metrics_arguments=extra_metrics_arguments, path_writer=path_writer, namespace=namespace, **config)
 
     def get_dense_layers(self):
         return self.net_state.dense_layers + self.net_output.dense_layers
@@ -88,7 +117,7 @@ class GNNnodeBased(BaseClass):
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
         targs = self.get_filtered_tensor(g, g.targets)
         loss_weights = self.get_filtered_tensor(g, g.sample_weights)
-        it, _, out = self.Loop(g, training=training)
+        it, _, out = self.Loop(g, training=training, _want_state=False)      # the state (N x Ds floats) is not needed here: stays on the device
         loss = self.loss_function(targs, out, **self.loss_args) * loss_weights
         return it, np.sum(loss), targs, out
 
@@ -177,11 +206,12 @@ class GNNnodeBased(BaseClass):
     def _prepare_loop(self, g: GraphTensor, loop) -> None:
         """Hook for subclasses that need more than the node mask on the device loop."""
 
-    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
-        """(k, state [N, Ds], out [M, T]) with k a float as in the reference (GNN.py:267, :280)."""
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None, _want_state: bool = True):
+        """(k, state [N, Ds], out [M, T]) with k a float as in the reference (GNN.py:267, :280).  _want_state=False (internal:
+        evaluate / test) leaves the state on the device and returns None in its place."""
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
         k, loop = self._run(g.device_graph(self.device), training, state0)
-        return k, loop.state(), loop.output()
+        return k, (loop.state() if _want_state else None), loop.output()
 
 
 class GNNedgeBased(GNNnodeBased):
@@ -189,7 +219,7 @@ class GNNedgeBased(GNNnodeBased):
     arcs selected by set_mask & output_mask (reference GNN.py:286-302; the pairing of index pairs and arc labels by position
     is the reference's)."""
 
-    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None, _want_state: bool = True):
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
         dev = g.device_graph(self.device)
         loop = self._device_loop(dev)
@@ -197,7 +227,7 @@ class GNNedgeBased(GNNnodeBased):
         if self.state_vect_dim > 0:
             loop.set_state0(state0, self.seed)
         k = self._train_forward(loop) if training else loop.run(False)
-        return k, loop.state(), loop.output()
+        return k, (loop.state() if _want_state else None), loop.output()
 
     def _prepare_loop(self, g: GraphTensor, loop, own_labels: bool = False) -> None:
         """own_labels: the loop runs on an LGNN-derived graph, which carries its own (widened) arc labels on the device."""
@@ -216,11 +246,11 @@ class GNNgraphBased(GNNnodeBased):
     def get_filtered_tensor(g: GraphTensor, inp):
         return np.asarray(inp, dtype=np.float32)      # targets are per graph: never filtered (reference GNN.py:313-315)
 
-    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None):
+    def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None, _want_state: bool = True):
         if g.NodeGraph is None: raise ValueError('WRONG GNN. NodeGraph is None: GNN is graph-based, while problem is non graph-based.')
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)
         if not g.loop_mask().all():
             # the reference multiplies NodeGraph [N, G] with the masked node outputs [M, T]: a shape error unless M == N
             raise ValueError('graph-based GNN needs set_mask and output_mask all True (NodeGraph rows must match node outputs)')
         k, loop = self._run(g.device_graph(self.device), training, state0)
-        return k, loop.state(), loop.readout(*g.nodegraph_csr())
+        return k, (loop.state() if _want_state else None), loop.readout(*g.nodegraph_csr())

@@ -46,13 +46,38 @@ class LGNN(BaseClass):
                               path_writer=path_writer or self.path_writer + '_copied/', namespace=namespace or 'LGNN')
 
     def save(self, path: str):
+        """Save the stack to folder <path>: one sub-folder per GNN + config.json (reference LGNN.py:83-103)."""
         import json, os
+        from GNN import losses, optimizers
+        from GNN.GNN import GNNnodeBased, GNNedgeBased, GNNgraphBased
         if path[-1] != '/': path += '/'
         for i, gnn in enumerate(self.gnns): gnn.save(f'{path}GNN{i}/')
         os.makedirs(path, exist_ok=True)
+        gnns_type = {GNNnodeBased: 'n', GNNedgeBased: 'a', GNNgraphBased: 'g'}[type(self.gnns[0])]
+        loss_name = getattr(self.loss_function, '__name__', None)
         with open(f'{path}config.json', 'w') as f:
-            json.dump({'get_state': self.get_state, 'get_output': self.get_output, 'loss_arguments': self.loss_args,
-                       'addressed_problem': self.addressed_problem}, f)
+            json.dump({'get_state': self.get_state, 'get_output': self.get_output, 'loss_function': loss_name if hasattr(losses, str(loss_name)) else None,
+                       'loss_arguments': self.loss_args, 'optimizer': optimizers.serialize(self.optimizer),
+                       'addressed_problem': self.addressed_problem, 'gnns_type': gnns_type}, f)
+
+    @classmethod
+    def load(cls, path: str, path_writer=None, namespace: str = 'LGNN', extra_metrics=None, extra_metrics_arguments=None):
+        """Load a stack saved by save() (reference LGNN.py:106-141, same arguments)."""
+        import json, os
+        from GNN import losses, optimizers
+        from GNN.GNN import GNNnodeBased, GNNedgeBased, GNNgraphBased
+        if path[-1] != '/': path += '/'
+        if path_writer is None: path_writer = f'{path}writer'
+        with open(f'{path}config.json') as f:
+            config = json.load(f)
+        optz = optimizers.deserialize(config.pop('optimizer', None))
+        loss_name = config.pop('loss_function', None)
+        loss = getattr(losses, loss_name) if loss_name else None
+        gnn_cls = {'n': GNNnodeBased, 'a': GNNedgeBased, 'g': GNNgraphBased}[config.pop('gnns_type')]
+        folders = sorted((d for d in os.listdir(path) if d.startswith('GNN') and os.path.isdir(f'{path}{d}')), key=lambda d: int(d[3:]))
+        gnns = [gnn_cls.load(f'{path}{d}', path_writer=f'{path_writer}{namespace} - {d}/', namespace='GNN') for d in folders]
+        return cls(gnns=gnns, optimizer=optz, loss_function=loss, extra_metrics=extra_metrics,
+                   extra_metrics_arguments=extra_metrics_arguments, path_writer=path_writer, namespace=namespace, **config)
 
     # ---- weights ------------------------------------------------------------------------------------------------------
     def get_dense_layers(self):

@@ -220,6 +220,40 @@ class Sequential:
         return self.device_mlp().forward(np.asarray(x, dtype=np.float32))
 
 
+def sequential_config(model: Sequential) -> list:
+    """JSON-able architecture of a Sequential (stands in for the SavedModel of reference GNN.py:100-101); initialisers that are
+    callables are stored as 'zeros' (the weights are saved beside the architecture anyway)."""
+    name = lambda spec: spec if isinstance(spec, str) else 'zeros'
+    out = []
+    for l in model.layers:
+        if isinstance(l, Dense):
+            out.append({'type': 'Dense', 'units': l.units, 'activation': l.activation, 'kernel_initializer': name(l.kernel_initializer),
+                        'bias_initializer': name(l.bias_initializer), 'input_shape': list(l.input_shape) if l.input_shape is not None else None})
+        elif isinstance(l, BatchNormalization):
+            out.append({'type': 'BatchNormalization', 'epsilon': l.epsilon, 'momentum': l.momentum})
+        else:
+            out.append({'type': type(l).__name__, 'rate': float(l.rate)})
+    return out
+
+
+def sequential_from_config(config: list, weights=None) -> Sequential:
+    layers = []
+    for c in config:
+        if c['type'] == 'Dense':
+            layers.append(Dense(c['units'], c['activation'], c['kernel_initializer'], c['bias_initializer'],
+                                input_shape=tuple(c['input_shape']) if c['input_shape'] is not None else None))
+        elif c['type'] == 'BatchNormalization':
+            layers.append(BatchNormalization(c['epsilon'], c['momentum']))
+        elif c['type'] in ('Dropout', 'AlphaDropout'):
+            layers.append({'Dropout': Dropout, 'AlphaDropout': AlphaDropout}[c['type']](c['rate']))
+        else:
+            raise ValueError(f"unknown layer type {c['type']!r}")
+    model = Sequential(layers)
+    if weights is not None:
+        model.set_weights(weights)
+    return model
+
+
 def clone_model(model: Sequential, copy_weights: bool = False) -> Sequential:
     """Fresh Sequential with the same architecture (stands in for tf.keras.models.clone_model, reference GNN.py:80-81)."""
     layers = []

@@ -51,3 +51,14 @@ class SGD(Optimizer):
             self._vel[i] = self.momentum * self._vel[i] - self.learning_rate * np.asarray(g, np.float64)
             out.append((np.asarray(p, np.float64) + self._vel[i]).astype(np.float32))
         return out
+
+
+def serialize(opt) -> dict:
+    """{'class_name', 'config'} (stands in for tf.keras.optimizers.serialize, reference GNN.py:105)."""
+    return {'class_name': type(opt).__name__, 'config': opt.get_config()} if isinstance(opt, Optimizer) else None
+
+
+def deserialize(d):
+    if d is None:
+        return None
+    return {'Adam': Adam, 'SGD': SGD}[d['class_name']](**d['config'])

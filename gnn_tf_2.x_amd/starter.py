@@ -5,7 +5,7 @@ names (`graphs, gTr, gVa, gTe, gnn, lgnn`), models running on the MI355X engine.
     >>> gnn.test(gTe)            # forward Loop / evaluate / test run on the GPU
     >>> lgnn.test(gTe)
     >>> gnn.train(gTr, 20, gVa)  # gradients on the GPU (gnn_loop_train_step), Adam on the host
-`lgnn.train` supports training_mode='serial'; the joint modes are not implemented yet.
+`lgnn.train` supports training_mode='serial' | 'parallel' | 'residual' (reference LGNN.py:293-344).
 """
 from __future__ import annotations
 

@@ -236,3 +236,40 @@ def test_halo_plan_on_host():
     # row 64 (first owned row of rank 1) reads node 63 = the boundary row of rank 0 -> slot 64 + 0 * 1 + 0; the others are own rows
     assert h['adj_src'][0] == 64 and list(h['adj_src'][1:]) == list(range(0, 63))
     assert h['nodes'].shape == (64 + 4, 2) and np.array_equal(h['nodes'][64], nodes[63]) and np.array_equal(h['nodes'][:64], nodes[64:128])
+
+
+def test_save_load_round_trip(tmp_path):
+    """GNN.save / GNN.load and LGNN.save / LGNN.load (reference GNN.py:93-149, LGNN.py:83-141): architecture, weights, optimizer and
+    loss come back; no pickled objects in the files."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNnodeBased, GNNgraphBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import MLP, AlphaDropout, Dropout, set_seed
+    set_seed(3)
+    st = MLP(7, [5, 3], 'selu', 'lecun_normal', 'lecun_normal', dropout_rate=0.2, dropout_pos=[0, 1], alphadropout=True)
+    ou = MLP(3, [2], 'softmax', 'glorot_normal', 'zeros', dropout_rate=0.1, dropout_pos=0, batch_normalization=False)
+    gnn = GNNnodeBased(net_state=st, net_output=ou, optimizer=optimizers.Adam(0.01, beta_1=0.8), loss_function=losses.categorical_crossentropy,
+                       loss_arguments={'from_logits': True}, state_vect_dim=0, max_iteration=7, threshold=0.02, addressed_problem='c',
+                       path_writer=str(tmp_path / 'w'))
+    gnn.save(str(tmp_path / 'm'))
+    assert not any(f.endswith('.pkl') for f in os.listdir(tmp_path / 'm'))
+    np.load(str(tmp_path / 'm' / 'net_state.npz'), allow_pickle=False).close()
+    back = GNNnodeBased.load(str(tmp_path / 'm'), path_writer=str(tmp_path / 'w2'))
+    assert (back.max_iteration, back.state_threshold, back.state_vect_dim, back.addressed_problem) == (7, 0.02, 0, 'c')
+    assert back.loss_function is losses.categorical_crossentropy and back.loss_args == {'from_logits': True}
+    assert isinstance(back.optimizer, optimizers.Adam) and back.optimizer.get_config() == gnn.optimizer.get_config()
+    for a, b in ((gnn.net_state, back.net_state), (gnn.net_output, back.net_output)):
+        assert [type(l).__name__ for l in a.layers] == [type(l).__name__ for l in b.layers]
+        assert a.activations == b.activations and a.batch_normalization == b.batch_normalization
+        assert all(np.array_equal(x, y) for x, y in zip(a.get_weights(), b.get_weights()))
+        assert a.dropout_rates() == b.dropout_rates()
+    assert isinstance(back.net_state.layers[0], AlphaDropout) and isinstance(back.net_output.layers[0], Dropout)
+    mk = lambda: GNNgraphBased(net_state=MLP(7, [3], 'tanh', 'glorot_normal', 'zeros'), net_output=MLP(3, [2], 'softmax', 'glorot_normal', 'zeros'),
+                               optimizer=optimizers.SGD(0.1) if hasattr(optimizers, 'SGD') else optimizers.Adam(), loss_function=losses.mse, loss_arguments=None,
+                               state_vect_dim=0, max_iteration=3, threshold=0.1, addressed_problem='c', path_writer=str(tmp_path / 'w3'))
+    lg = LGNN([mk(), mk()], False, True, optimizers.Adam(), losses.mse, None, 'c', path_writer=str(tmp_path / 'w4'))
+    lg.save(str(tmp_path / 'l'))
+    lb = LGNN.load(str(tmp_path / 'l'), path_writer=str(tmp_path / 'w5'))
+    assert lb.LAYERS == 2 and (lb.get_state, lb.get_output) == (False, True) and isinstance(lb.gnns[0], GNNgraphBased)
+    for g0, g1 in zip(lg.gnns, lb.gnns):
+        assert all(np.array_equal(x, y) for x, y in zip(g0.net_state.get_weights(), g1.net_state.get_weights()))
