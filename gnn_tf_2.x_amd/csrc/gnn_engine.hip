@@ -1111,7 +1111,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS + 4);   // + barrier counter / status of the persistent loop
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 2);        // k, status word of the persistent loop
-    if (!rc) rc = dev_alloc(&l->tile_ctr, ((size_t)max_iter + 1 + 3) & ~(size_t)3);
+    if (!rc) rc = dev_alloc(&l->tile_ctr, (2 * ((size_t)max_iter + 1) + 3) & ~(size_t)3);      // per body: full-tile launch, partial-tile launch
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, 2 * sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc) l->kfinal_host[1] = 0;
     if (!rc && hipHostMalloc((void **)&l->gate_host, sizeof(int) * (size_t)world * GNN_FLAG_WORDS) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
@@ -1326,7 +1326,7 @@ static int loop_begin(gnn_loop *l, bool fused)
     hipStream_t st = l->stream;
     int rc = 0;
     HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P * GNN_FLAG_WORDS, st));
-    HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * (((size_t)l->max_iter + 1 + 3) & ~(size_t)3), st));
+    HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * ((2 * ((size_t)l->max_iter + 1) + 3) & ~(size_t)3), st));
     float *own0 = l->state[0] + (size_t)l->own_off * l->Ds;
     if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
         HIPCHK(hipMemcpyAsync(own0, l->D ? l->state_init : g->nodes + (size_t)g->own_off * g->NL,

@@ -40,6 +40,8 @@ struct GnnFusedArgs {
     // loads of the unrolled layers are buffer_load(rsrc, lane * 16, scalar offset) without any per-load vector address arithmetic
     const int *Ws_base;
     int ws_bytes, ws_off[GNN_FUSED_MAXL];
+    int tile_base;           // first tile of this launch (tickets count from it)
+    int full_tiles;          // 1: state width 64 and n_rows a multiple of 32 - launch the full-tile specialisation of the kernel
     int variant;             // tuning switches (bit 0: raised wave priority during the gather); fixed in the shipped build
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;

@@ -255,6 +255,8 @@ static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs
     a.world = P;
     a.stamps = nullptr;
     a.wstride = 1;
+    a.tile_base = 0;
+    a.full_tiles = 0;
     return GNN_OK;
 }
 
@@ -302,14 +304,31 @@ int gnn_fused_iteration(gnn_loop *l, int k)
 #endif
     a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_rounds : 0;   // only when every wave has several tiles to run
     const size_t lds = lds_bytes(p);
+    auto go = [&](const GnnFusedArgs &aa, unsigned gr) -> bool {
+        if (split) {
+            if (p.layers == 1) return gnn_fused_launch_s1(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
+            if (p.layers == 2) return gnn_fused_launch_s2(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
+            return gnn_fused_launch_s3(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
+        }
+        if (p.layers == 1) return gnn_fused_launch_l1(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
+        if (p.layers == 2) return gnn_fused_launch_l2(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
+        return gnn_fused_launch_l3(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
+    };
     bool ok = false;
-    if (split) {
-        if (p.layers == 1) ok = gnn_fused_launch_s1(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
-        else if (p.layers == 2) ok = gnn_fused_launch_s2(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
-        else ok = gnn_fused_launch_s3(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
-    } else if (p.layers == 1) ok = gnn_fused_launch_l1(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
-    else if (p.layers == 2) ok = gnn_fused_launch_l2(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
-    else ok = gnn_fused_launch_l3(p.act, p.NT, p.NTL, a, grid, lds, l->stream);
+    const int64_t n_full = g->n_rows / 32;
+    if (l->Ds == 64 && p.NTL == 2 && n_full >= 1) {
+        // full tiles through the full-tile specialisation (no generic paths compiled in); a partial last tile through a second,
+        // one-tile launch of the general kernel with its own ticket counter
+        GnnFusedArgs af = a;
+        af.full_tiles = 1; af.n_rows = n_full * 32; af.tile_base = 0;
+        ok = go(af, (unsigned)std::min<size_t>((size_t)n_cu, (size_t)n_full));
+        if (ok && g->n_rows % 32) {
+            GnnFusedArgs ar = a;
+            ar.tile_base = (int)n_full; ar.tile_ctr = l->tile_ctr + (l->max_iter + 1) + k; ar.stagger = 0;
+            ok = go(ar, 1);
+        }
+    } else
+        ok = go(a, grid);
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);
 #ifdef GNN_DIAG
     if (a.stamps) {

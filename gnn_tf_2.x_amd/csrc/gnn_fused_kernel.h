@@ -958,7 +958,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N])
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
 }
 
-template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
+// FULL: state width 64 and only full 32-node tiles (the host sends a partial last tile to a second, one-tile launch of the general
+// kernel): the guarded generic paths are not compiled in at all, which frees registers and scalar registers for the tuned ones.
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT, bool FULL = false>
 __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedArgs a0)
 {
     const GnnFusedArgs &a = a0;      // (shadowed inside the tile loop)
@@ -997,12 +999,12 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // (Serving the tickets heaviest-tile-first was measured: 1 % slower on the BASELINE graph.)
     int tile = 0, next_tile = 0;
     if (lane == 0) { tile = atomicAdd(a.tile_ctr, 1); next_tile = atomicAdd(a.tile_ctr, 1); }
-    tile = __builtin_amdgcn_readfirstlane(tile);
-    next_tile = __builtin_amdgcn_readfirstlane(next_tile);
+    tile = __builtin_amdgcn_readfirstlane(tile) + a.tile_base;
+    next_tile = __builtin_amdgcn_readfirstlane(next_tile) + a.tile_base;
     int ip_cur = tile_rowptr_clamp(a, tile, lane, tile_rowptr_request(a, tile, lane));
     int src_cur = 0;
     float w_cur = 0.0f;
-    if (Ds == 64) tile_first_ids(a, ip_cur, lane, src_cur, w_cur);
+    if (FULL || Ds == 64) tile_first_ids(a, ip_cur, lane, src_cur, w_cur);
   for (;;) {
     const int64_t i0 = (int64_t)tile * 32;
     if (i0 >= a.n_rows) break;                        // wave-uniform; no workgroup barrier anywhere in the kernel
@@ -1033,12 +1035,15 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     int *ipt = reinterpret_cast<int *>(lds + (size_t)GNN_FUSED_WAVES * 32 * KP + 32) + wave * 36;
     if (lane <= 32) ipt[lane] = ip_cur;               // requested during the previous tile
     const int ip_next_raw = tile_rowptr_request(a, next_tile, lane);      // row pointers of the NEXT tile: on their way during the gather
-    const bool fast64 = (Ds == 64) && (nvalid == 32);     // wave-uniform: the BASELINE shape takes the unguarded paths
+    const bool fast64 = FULL || ((Ds == 64) && (nvalid == 32));     // wave-uniform: the BASELINE shape takes the unguarded paths
     // the gather is a chain of few instructions and long memory waits: with a raised priority its loads are issued ahead of the
     // SIMD partner's dense VALU / MFMA stream instead of behind it
     if (a.variant & 1) __builtin_amdgcn_s_setprio(3);
-    if (fast64) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
-    else load_tile_generic(a, X, ipt, i0, lane, nvalid, KP, c_aggs);
+    if constexpr (FULL) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
+    else {
+        if (fast64) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
+        else load_tile_generic(a, X, ipt, i0, lane, nvalid, KP, c_aggs);
+    }
     if (a.variant & 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     GNN_STAMP(2);
@@ -1055,8 +1060,11 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
             layer0_split<NTL, false>(xr, wrs, wv, a.ws_off[0], a.chunks0, out, ep, half);
         } else {
             f32x16 h1[NT];
-            if (Ds == 64) layer0_split<NT, true>(xr, wrs, wv, a.ws_off[0], a.chunks0, h1, hb, half);    // 16-byte aligned tile layout
-            else layer0_split<NT, false>(xr, wrs, wv, a.ws_off[0], a.chunks0, h1, hb, half);
+            if constexpr (FULL) layer0_split<NT, true>(xr, wrs, wv, a.ws_off[0], a.chunks0, h1, hb, half);
+            else {
+                if (Ds == 64) layer0_split<NT, true>(xr, wrs, wv, a.ws_off[0], a.chunks0, h1, hb, half);    // 16-byte aligned tile layout
+                else layer0_split<NT, false>(xr, wrs, wv, a.ws_off[0], a.chunks0, h1, hb, half);
+            }
             GNN_STAMP(3);
             GNN_STAMP(4);
             if constexpr (LAYERS == 2) {
@@ -1098,7 +1106,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     const int ip_next = tile_rowptr_clamp(a, next_tile, lane, ip_next_raw);
     int src_next = 0;
     float w_next = 0.0f;
-    if (Ds == 64) tile_first_ids(a, ip_next, lane, src_next, w_next);
+    if (FULL || Ds == 64) tile_first_ids(a, ip_next, lane, src_next, w_next);
     bool finished = false;
     if constexpr (SPLIT && NTL == 2) {
         if (fast64) {                                         // registers -> norms, LDS (16-byte pieces), row stores
@@ -1112,7 +1120,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
             finished = true;
         }
     }
-    if (!finished) {
+    if (!(FULL && SPLIT && NTL == 2) && !finished) {
 #pragma unroll
         for (int jt = 0; jt < NTL; ++jt) {
             if (a.bn_scale) tile_epilogue<ACT, true, SPLIT, true, SPLIT>(out[jt], ep, ep + 32 * NTL, ep + 64 * NTL, jt, half);
@@ -1126,30 +1134,43 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         GNN_STAMP(6);
-        if (fast64) check_store_fast64(a, X, i0, lane, KP, c_aggs);
-        else check_store_generic(a, X, i0, lane, nvalid, KP, c_aggs);
+        if constexpr (FULL) check_store_fast64(a, X, i0, lane, KP, c_aggs);
+        else {
+            if (fast64) check_store_fast64(a, X, i0, lane, KP, c_aggs);
+            else check_store_generic(a, X, i0, lane, nvalid, KP, c_aggs);
+        }
     }
     GNN_STAMP(7);
 #undef GNN_STAMP
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next tile re-uses this wave's LDS region
     tile = next_tile;
-    next_tile = __builtin_amdgcn_readfirstlane(next2_tile);
+    next_tile = __builtin_amdgcn_readfirstlane(next2_tile) + a0.tile_base;
     ip_cur = ip_next; src_cur = src_next; w_cur = w_next;
   }
 }
 
-template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
-inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT, bool FULL>
+inline void launch_one(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
     static bool raised[64] = {false};   // dynamic LDS above 64 KiB has to be requested once per kernel AND device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT, SPLIT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
-    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
+    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
+}
+
+// a.full_tiles: the host asks for the full-tile specialisation (state width 64, a.n_rows a multiple of 32); it exists for NTL == 2
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
+inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
+{
+    if constexpr (NTL == 2) {
+        if (a.full_tiles) { launch_one<LAYERS, NT, NTL, ACT, SPLIT, true>(a, grid, lds_bytes, st); return; }
+    }
+    launch_one<LAYERS, NT, NTL, ACT, SPLIT, false>(a, grid, lds_bytes, st);
 }
 
 // (NT, NTL) pairs that are instantiated; gnn_fused.hip rounds every net up to one of them
