@@ -121,6 +121,14 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
                 }
         for (int j = 0; j < n_out; ++j) img[p.b_off[l] + j] = b[j];
         // split image: [chunk][out tile][piece][lane][8 bf16]; element i of lane (m, h) is k(h, i) of gnn_fused_kernel.h
+        // Folded SELU between the dense layers of the split path (gnn_fused_kernel.h, GNN_S1_E): a layer whose OUTPUT feeds the
+        // folded activation is scaled by log2(e) (so is its bias, at staging), a layer whose INPUT comes from it by scale / log2(e).
+        float fold = 1.0f;
+        if (p.act == GNN_ACT_SELU && m->n_layers > 1) {
+            const double LOG2E = 1.44269504088896341, SCALE = 1.0507009873554805;
+            const bool in_folded = l > 0, out_folded = l < m->n_layers - 1;
+            fold = (float)((in_folded ? SCALE / LOG2E : 1.0) * (out_folded ? LOG2E : 1.0));
+        }
         uint32_t *sp = simg.data() + p.s_off[l];
         for (int c = 0; c < p.chunks[l]; ++c)
             for (int jt = 0; jt < nt; ++jt)
@@ -131,6 +139,7 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
                         if (l == 0 && p.pad) k = k < lab ? k : (k < lab + p.pad ? n_in : k - p.pad);   // LDS column -> concat column (hole: zero)
                         const int j = 32 * jt + (lane & 31);
                         float v = (k < n_in && j < n_out) ? W[(size_t)k * n_out + j] : 0.0f;
+                        v *= fold;
                         for (int pc = 0; pc < 3; ++pc) {          // truncation split: v == p0 + p1 + p2 exactly
                             uint32_t bits;
                             memcpy(&bits, &v, 4);

