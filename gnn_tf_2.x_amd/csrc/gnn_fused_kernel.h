@@ -29,6 +29,11 @@
 #include "gnn_fused.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// two gather batches in flight per lane group (load_tile_fast64, DEEP): measured 4 % SLOWER than one batch (round 2) - kept as a
+// compile-time option for re-measurement, off in the shipped library
+#ifndef GNN_FUSED_DEEP_GATHER
+#define GNN_FUSED_DEEP_GATHER false
+#endif
 
 namespace gnn_fused_dev {
 
@@ -728,7 +733,8 @@ __device__ __forceinline__ void gather_batch(int my_src, float my_w, __amdgpu_bu
 // AL16: rows of the tile and the aggregated-state block are 16-byte aligned (split arithmetic): one ds_write_b128 per row piece
 // PADDED: the zero padding of the tile (columns behind the concat, alignment hole) is already in place: nothing in a tile's life
 // writes those columns, so the full-tile kernel zeroes them once per wave instead of once per tile
-template <bool AL16, bool PADDED = false>
+// DEEP: TWO batches of GB rows in flight per lane group (see the gather loop)
+template <bool AL16, bool PADDED = false, bool DEEP = false>
 __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
                                                  int KP, int c_aggs, int my_src, float my_w)
 {
@@ -773,6 +779,53 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
     }
     // (my_src, my_w): ids / weights of the group's first batch, requested during the previous tile (tile_first_ids)
     int base = e_begin;
+  if constexpr (DEEP) {
+    // Two register sets A / B of GB rows each: while one set is consumed the other one is in flight, and a consumed set is
+    // requested again at once for the batch two ahead, so about 2 GB rows (32 KiB per wave) are in flight all through the gather
+    // instead of draining to zero before every batch.  (Measured: the round trips get proportionally longer - the memory system,
+    // not the number of requests a wave keeps in flight, paces the gather phases - and the guards cost issue slots: 0.725 vs 0.698 ms.)
+    float wa[GB], wb[GB];
+    v4f xa[GB], xb[GB];
+    int src_b = 0, src_a2 = 0, src_b2 = 0;             // ids of batch 1 (B), batch 2 (next A), batch 3 (next B)
+    float w_b = 0.0f, w_a2 = 0.0f, w_b2 = 0.0f;
+    auto ids = [&](int first, int &sr, float &wt) {
+        const int nb = first + gl;
+        sr = 0; wt = 0.0f;
+        if (nb < e_end) { sr = gload1(a.adj_src + nb); wt = gload1(a.adj_w + nb); }
+    };
+    ids(e_begin + GB, src_b, w_b);
+    gather_batch<GB>(my_src, my_w, rsrc, voff0, wa, xa, std::make_integer_sequence<int, GB>{});      // A <- batch 0
+    ids(e_begin + 2 * GB, src_a2, w_a2);
+    gather_batch<GB>(src_b, w_b, rsrc, voff0, wb, xb, std::make_integer_sequence<int, GB>{});        // B <- batch 1
+    ids(e_begin + 3 * GB, src_b2, w_b2);
+    while (base < e_end) {                                                   // trip count differs between the four groups
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            if (base + u < e_end) {
+                GNN_ROW_BOUNDARY(base + u)
+                acc01 = __builtin_elementwise_fma(v2f{wa[u], wa[u]}, xa[u].lo, acc01);
+                acc23 = __builtin_elementwise_fma(v2f{wa[u], wa[u]}, xa[u].hi, acc23);
+            }
+        }
+        if (base + 2 * GB < e_end) {                                         // A <- batch two ahead
+            gather_batch<GB>(src_a2, w_a2, rsrc, voff0, wa, xa, std::make_integer_sequence<int, GB>{});
+            ids(base + 4 * GB, src_a2, w_a2);
+        }
+#pragma unroll
+        for (int u = 0; u < GB; ++u) {
+            if (base + GB + u < e_end) {
+                GNN_ROW_BOUNDARY(base + GB + u)
+                acc01 = __builtin_elementwise_fma(v2f{wb[u], wb[u]}, xb[u].lo, acc01);
+                acc23 = __builtin_elementwise_fma(v2f{wb[u], wb[u]}, xb[u].hi, acc23);
+            }
+        }
+        if (base + 3 * GB < e_end) {                                         // B <- batch two ahead
+            gather_batch<GB>(src_b2, w_b2, rsrc, voff0, wb, xb, std::make_integer_sequence<int, GB>{});
+            ids(base + 5 * GB, src_b2, w_b2);
+        }
+        base += 2 * GB;
+    }
+  } else {
     for (; base + GB <= e_end; base += GB) {                                 // full batches: no guards
         float w[GB];
         v4f x[GB];
@@ -803,6 +856,7 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
             }
         }
     }
+  }
 #undef GNN_ROW_BOUNDARY
     for (; node < node_end; ++node) {                                        // last row with entries, then empty rows
         float *xr = xo + node * KP;
@@ -1052,7 +1106,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // the gather is a chain of few instructions and long memory waits: with a raised priority its loads are issued ahead of the
     // SIMD partner's dense VALU / MFMA stream instead of behind it
     if (a.variant & 1) __builtin_amdgcn_s_setprio(3);
-    if constexpr (FULL) load_tile_fast64<SPLIT, true>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
+    if constexpr (FULL) load_tile_fast64<SPLIT, true, GNN_FUSED_DEEP_GATHER>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
     else {
         if (fast64) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
         else load_tile_generic(a, X, ipt, i0, lane, nvalid, KP, c_aggs);
