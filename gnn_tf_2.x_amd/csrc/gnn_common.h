@@ -183,6 +183,8 @@ struct gnn_loop {
     int *flags = nullptr;                   // [(max_iter+2), world, GNN_FLAG_WORDS]
     int *tile_ctr = nullptr;                // fused path: one tile counter per iteration [max_iter + 1]
     int *kfinal_dev = nullptr, *kfinal_host = nullptr;   // device [4]: k, persistent-loop barrier counter, its status word, pad; host mirror [4]
+    bool small_words_clean = false;         // the double-buffered gate words of the persistent loop are zero / in their run-parity state
+    unsigned small_runs = 0;
     bool small_disabled = false;            // the persistent small-graph loop gave up once on this loop: keep to per-body launches
     int kfinal = -1;
     bool have_state0 = false, ran = false;
@@ -228,5 +230,5 @@ int gnn_fused_prepare(gnn_loop *l);
 int gnn_fused_pack(gnn_mlp *m, int nlc);
 int gnn_fused_iteration(gnn_loop *l, int k);
 bool gnn_small_supported(const gnn_loop *l);   // persistent small-graph loop (gnn_small.hip): all bodies in one launch
-int gnn_small_run(gnn_loop *l);
+int gnn_small_run(gnn_loop *l, bool *output_done);
 void gnn_fused_release(gnn_mlp *m);

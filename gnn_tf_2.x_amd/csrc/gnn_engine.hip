@@ -1326,6 +1326,7 @@ static int loop_begin(gnn_loop *l, bool fused)
     hipStream_t st = l->stream;
     int rc = 0;
     HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (size_t)(l->max_iter + 2) * P * GNN_FLAG_WORDS, st));
+    l->small_words_clean = false;       // the persistent loop's gate words share this block
     HIPCHK(hipMemsetAsync(l->tile_ctr, 0, sizeof(int) * ((2 * ((size_t)l->max_iter + 1) + 3) & ~(size_t)3), st));
     float *own0 = l->state[0] + (size_t)l->own_off * l->Ds;
     if (g->n_rows)   // state <- nodes (GNN.py:265) or the injected / drawn initial state (GNN.py:262)
@@ -1369,7 +1370,7 @@ static int loop_gate_closed(gnn_loop *l, int k, bool *closed)
 }
 
 // k, apply_filters + net_output on the owned masked rows (GNN.py:275-279)
-static int loop_finish(gnn_loop *l, bool finalize)
+static int loop_finish(gnn_loop *l, bool finalize, bool output_done)
 {
     gnn_graph *g = l->g;
     hipStream_t st = l->stream;
@@ -1378,7 +1379,8 @@ static int loop_finish(gnn_loop *l, bool finalize)
         hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, l->world, l->max_iter, l->kfinal_dev);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, (finalize ? 1 : 2) * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (finalize) HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (output_done) return GNN_OK;     // (the persistent loop wrote k into the pinned host words and ran the output stage itself)
     const float *own0 = l->state[0] + (size_t)l->own_off * l->Ds, *own1 = l->state[1] + (size_t)l->own_off * l->Ds;
     const float *nodes_own = g->nodes + (size_t)g->own_off * g->NL;
 
@@ -1437,7 +1439,8 @@ static int loop_collect(gnn_loop *l, float *k_out)
 {
     l->kfinal = *l->kfinal_host;
     l->ran = true;
-    HIPCHK(hipEventElapsedTime(&l->total_ms, l->ev_total[0], l->ev_total[1]));
+    l->total_ms = 0.f;
+    if (l->profiling) HIPCHK(hipEventElapsedTime(&l->total_ms, l->ev_total[0], l->ev_total[1]));
     l->avg_iter_ms = 0.f;
     l->n_iter_timed = 0;
     if (l->profiling) {
@@ -1470,14 +1473,15 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
     const int max_iter = ls[0]->max_iter;
     // small graphs: the initial state, the first condition and every body inside ONE persistent launch (gnn_small.hip)
     const bool small = n == 1 && fused[0] && gnn_small_supported(ls[0]);
+    bool output_done = false;
     for (int r = 0; r < n; ++r) {
-        HIPCHK(hipEventRecord(ls[r]->ev_total[0], ls[r]->stream));
+        if (ls[r]->profiling) HIPCHK(hipEventRecord(ls[r]->ev_total[0], ls[r]->stream));
         if (!small && (rc = loop_begin(ls[r], fused[r]))) return rc;
     }
     for (int r = 0; r < n && !small; ++r) if ((rc = loop_exchange(ls[r], 0, 0))) return rc;
     if (small) {
         ls[0]->kfinal_host[1] = 0;
-        if ((rc = gnn_small_run(ls[0]))) return rc;
+        if ((rc = gnn_small_run(ls[0], &output_done))) return rc;
     }
     for (int k = 0; k < max_iter && !small; ++k) {
         for (int r = 0; r < n; ++r) if ((rc = loop_body(ls[r], k, fused[r]))) return rc;
@@ -1494,12 +1498,13 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
         }
     }
     for (int r = 0; r < n; ++r) {
-        if ((rc = loop_finish(ls[r], !small))) return rc;
-        HIPCHK(hipEventRecord(ls[r]->ev_total[1], ls[r]->stream));
+        if ((rc = loop_finish(ls[r], !small, output_done))) return rc;
+        if (ls[r]->profiling) HIPCHK(hipEventRecord(ls[r]->ev_total[1], ls[r]->stream));
     }
     for (int r = 0; r < n; ++r) HIPCHK(hipStreamSynchronize(ls[r]->stream));
     if (small && ls[0]->kfinal_host[1] != 0) {       // a barrier spin gave up (grid not resident?): repeat with one launch per body
         ls[0]->small_disabled = true;
+        ls[0]->small_words_clean = false;
         return run_loops(ls, n, k_out);
     }
     for (int r = 0; r < n; ++r) {

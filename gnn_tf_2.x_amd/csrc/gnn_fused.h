@@ -54,7 +54,17 @@ struct GnnSmallCtl {
     int *kfinal;             // receives the number of executed bodies
     int *flags;              // word [b]: barrier + gate of body b (low half arrivals, high half movers), zeroed before the launch
     int *status;             // = kfinal + 1: set to 1 by a workgroup whose barrier spin gave up, to 0 at the regular end
+    int *host_result;        // pinned host memory (zero-copy): [k, status] for the host, or nullptr
+    int *zero_words;         // the OTHER run's gate words (double-buffered by run parity): zeroed here for the next run
+    int n_words;
     int max_iter;
+    // output stage folded into the launch (apply_filters + a one-layer net_output, GNN.py:275-279; as k_out1), or out == nullptr
+    float *out;              // [n_masked, T]
+    const uint8_t *mask;     // [n_rows]
+    const int32_t *mask_pos; // [n_rows] position of a masked row among the masked rows
+    const float *nodes_own;  // node labels of the owned rows [n_rows, NL]
+    const float *ow, *ob, *obn_scale, *obn_shift;   // net_output: W [wf, T], b [T], BatchNormalization scale / shift or nullptr
+    int NL, NLc, T, oact;
 };
 bool gnn_small_launch(int layers, int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
                       hipStream_t st);

@@ -366,27 +366,50 @@ bool gnn_small_supported(const gnn_loop *l)
     return n_tiles >= 1 && n_tiles <= 256;                          // every tile resident at once (one wave each), with a wide margin
 }
 
-int gnn_small_run(gnn_loop *l)
+int gnn_small_run(gnn_loop *l, bool *output_done)
 {
     FusedPlan p;
     GnnFusedArgs a;
     int rc = fused_args(l, 0, false, p, a);                          // exact f32-MFMA arithmetic, unpadded tile layout
     if (rc) return rc;
+    const gnn_graph *g = l->g;
     a.gate = nullptr; a.flag_out = nullptr; a.tile_ctr = nullptr; a.stagger = 0;
     GnnSmallCtl c{};
     c.state0 = l->state[0]; c.state1 = l->state[1];
-    c.init = l->D ? l->state_init : l->g->nodes + (size_t)l->g->own_off * l->g->NL;      // D == 0: NL == Ds (GNN.py:265)
+    c.init = l->D ? l->state_init : g->nodes + (size_t)g->own_off * g->NL;      // D == 0: NL == Ds (GNN.py:265)
     c.kfinal = l->kfinal_dev;
-    c.flags = l->flags;
     c.status = l->kfinal_dev + 1;
+    c.host_result = l->kfinal_host;                                   // pinned, device-visible: no copy back
     c.max_iter = l->max_iter;
-    // the only words the kernel polls: one per body at the start of the flag block, zeroed as one 16-byte-multiple block
-    HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * (((size_t)l->max_iter + 2 + 3) & ~(size_t)3), l->stream));
-    const unsigned grid = (unsigned)((l->g->n_rows + 31) / 32);
+    // Gate words: one per body, double-buffered by run parity at the start of the flag block.  This launch polls its own half
+    // and zeroes the other half for the next run, so a run costs no memset; both halves are cleared by the host only after
+    // something else (a per-body run) has used the block.
+    const size_t n_words = ((size_t)l->max_iter + 2 + 3) & ~(size_t)3;
+    if (!l->small_words_clean) {
+        HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * 2 * n_words, l->stream));
+        l->small_words_clean = true;
+        l->small_runs = 0;
+    }
+    c.flags = l->flags + (l->small_runs & 1) * n_words;
+    c.zero_words = l->flags + ((l->small_runs & 1) ^ 1) * n_words;
+    c.n_words = (int)n_words;
+    ++l->small_runs;
+    // output stage inside the launch when it is the usual one-layer head (same condition as k_out1)
+    *output_done = false;
+    const gnn_mlp *ou = l->ou;
+    if (!l->edge_mode && g->n_masked && ou->n_layers == 1 && l->T <= 8) {
+        c.out = l->out; c.mask = g->sh->mask; c.mask_pos = g->sh->masked_rows + g->n_masked;
+        c.nodes_own = g->nodes + (size_t)g->own_off * g->NL;
+        c.ow = ou->W[0]; c.ob = ou->b[0];
+        c.obn_scale = ou->has_bn ? ou->bn_scale : nullptr; c.obn_shift = ou->has_bn ? ou->bn_shift : nullptr;
+        c.NL = g->NL; c.NLc = l->NLc; c.T = l->T; c.oact = ou->acts[0];
+        *output_done = true;
+    }
+    const unsigned grid = (unsigned)((g->n_rows + 31) / 32);
     const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 96 + 4);
-    const int rnd = l->g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
+    const int rnd = g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
     if (!gnn_small_launch(p.layers, p.act, p.kk0, rnd, a, c, grid, lds, l->stream))
         return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
     HIPCHK(hipGetLastError());
-    return GNN_OK;      // k and the status word travel in ONE 8-byte copy (loop_finish)
+    return GNN_OK;      // k and the status word are written straight into the pinned host words
 }

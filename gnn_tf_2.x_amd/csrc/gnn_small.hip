@@ -76,6 +76,9 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
 #pragma unroll
         for (int ss = 0; ss < 16; ++ss) w2[ss] = gload1(a0.Wp[2] + (size_t)ss * 64 + lane);
     }
+    // the gate words of the NEXT run (the other half of the double buffer): nobody reads them during this launch
+    if (blockIdx.x == 0)
+        for (int t = lane; t < c.n_words; t += 64) c.zero_words[t] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const unsigned n_wg = gridDim.x;
     // Grid barrier + gate in ONE word per body: after its write-through stores have drained, every workgroup adds
@@ -166,8 +169,59 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         go = arrive_and_gate(k + 1, moved);
     }
-    if (go < 0) return;
-    if (blockIdx.x == 0 && lane == 0) { c.kfinal[0] = k; c.kfinal[1] = 0; }   // executed bodies (GNN.py:267; every workgroup agrees), status ok
+    if (go < 0) {
+        if (c.host_result && lane == 0) c.host_result[1] = 1;
+        return;
+    }
+    if (blockIdx.x == 0 && lane == 0) {      // executed bodies (GNN.py:267; every workgroup agrees), status ok
+        c.kfinal[0] = k; c.kfinal[1] = 0;
+        if (c.host_result) { c.host_result[0] = k; c.host_result[1] = 0; }
+    }
+    // ---- apply_filters + one-layer net_output on the tile's masked rows (GNN.py:275-279), arithmetic as k_out1: k-ordered fmaf
+    // chain per output, bias, softmax / activation, BatchNormalization ------------------------------------------------------
+    if (c.out && lane < nvalid && c.mask[i0 + lane]) {
+        const float *sfin = ((k & 1) ? c.state1 : c.state0) + (a0.row_begin + i0 + lane) * Ds;     // this tile's own stores
+        const float *nod = c.nodes_own + (i0 + lane) * c.NL;
+        const int wf = Ds + c.NLc, T = c.T;
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = 0.0f;
+        for (int kk = 0; kk < wf; ++kk) {
+            const float x = kk < Ds ? sload1<true>(sfin + kk) : gload1(nod + (kk - Ds));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < T) y[j] = __builtin_fmaf(x, gload1(c.ow + kk * T + j), y[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < T) y[j] = y[j] + gload1(c.ob + j);
+        float v[8];
+        if (c.oact == GNN_ACT_SOFTMAX) {
+            float mx = y[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                if (q < T) mx = y[q] > mx ? y[q] : mx;
+            float sum = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < T) { v[q] = gnn_expf(y[q] - mx); sum = sum + v[q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < T) v[q] = __fdiv_rn(v[q], sum);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < T) v[q] = gnn_act(y[q], c.oact);
+        }
+        float *o = c.out + (int64_t)c.mask_pos[i0 + lane] * T;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < T) {
+                float r = v[q];
+                if (c.obn_scale) { const float t2 = r * gload1(c.obn_scale + q); r = t2 + gload1(c.obn_shift + q); }
+                o[q] = r;
+            }
+    }
 }
 
 template <int LAYERS, int ACT>
