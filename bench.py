@@ -151,6 +151,8 @@ def main():
     ap.add_argument('--impl', type=int, default=2, help='2: fused kernel, split bf16 MFMA (default, what the engine runs by default); '
                                                        '1: fused kernel, bit-exact f32 MFMA; 0: one kernel per TF op')
     ap.add_argument('--act', default='selu', help='net_state activation (experiments; the BASELINE config is selu)')
+    ap.add_argument('--exchange', choices=['full', 'halo'], default='full',
+                    help='N > 1: all-gather of whole shards (default) or of boundary rows only (gnn_graph_create_halo)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=20)
     args = ap.parse_args()
@@ -179,8 +181,13 @@ def main():
     rb, nr, indptr, adj_src, adj_w, arc_w, arc_lab = engine.shard_csr(n, rank, world, s['indptr'], s['adj_src'], s['adj_w'],
                                                                         s['arc_w'], s['arc_labels_csr'])
     n_arcs_local = len(adj_src)
-    graph = engine.Graph(n, indptr, adj_src, adj_w, arc_w, arc_lab, s['nodes'], np.ones(nr, np.uint8), row_begin=rb,
-                         device=local_rank)
+    if world > 1 and args.exchange == 'halo':
+        h = engine.shard_halo(n, rank, world, s['indptr'], s['adj_src'], s['nodes'])
+        graph = engine.Graph.halo(n, rank, world, h['block'], h['send_rows'], indptr, h['adj_src'], adj_w, arc_w, arc_lab, h['nodes'],
+                                  np.ones(nr, np.uint8), device=local_rank)
+    else:
+        graph = engine.Graph(n, indptr, adj_src, adj_w, arc_w, arc_lab, s['nodes'], np.ones(nr, np.uint8), row_begin=rb,
+                             device=local_rank)
     mst = engine.Mlp(st['weights'], st['activations'], True, device=local_rank)
     mou = engine.Mlp(ou['weights'], ou['activations'], True, device=local_rank)
     loop = engine.Loop(graph, mst, mou, d, args.max_iter, 0.0, comm)
@@ -273,7 +280,7 @@ def main():
                                    f'max_iter={args.max_iter}, threshold=0 (all iterations run); the loop-invariant label aggregates '
                                    f'(GNN.py:259, :263; 0.2 ms) are kept between Loops until the labels change, see cold_aggregates_ms_per_step',
                        'iterations_per_step': k_total / args.steps,
-                       'parallelism': f'node-range shards x{world}, RCCL all-gather of state rows per iteration' if world > 1 else 'single GPU',
+                       'parallelism': (f'node-range shards x{world}, RCCL all-gather of ' + ('boundary' if args.exchange == 'halo' else 'owned') + ' state rows per iteration') if world > 1 else 'single GPU',
                        'impl': {2: 'fused gather+MLP kernel, dense layers on the bf16 MFMA with fp32 operands cut into 3 exact bf16 '
                                    'pieces (6 piece products, fp32 accumulate; error per product <= 3*2^-24)',
                                 1: 'fused gather+MLP kernel, dense layers on the f32 MFMA (bit-identical to the oracle)',
