@@ -96,8 +96,31 @@ __global__ void k_act_fwd(int64_t n, int F, const float *z, int act, float *a)
     }
 }
 
-// dz = da * act'(z) (softmax: a * (da - sum da a) per row); in place on d.  Every derivative is a function of the OUTPUT a
-// alone (selu: z > 0 <=> a > 0 and scale * alpha * e^z = a + scale * alpha; elu: e^z = a + 1), so z is not kept.
+// act'(z) as a function of the OUTPUT a alone (selu: z > 0 <=> a > 0 and scale * alpha * e^z = a + scale * alpha; elu: e^z = a + 1),
+// so z is not kept.  Softmax is not elementwise: k_act_bwd.
+__device__ __forceinline__ float act_grad(float aa, int act)
+{
+    switch (act) {
+    case GNN_ACT_RELU: return aa > 0.0f ? 1.0f : 0.0f;
+    case GNN_ACT_SELU: return aa > 0.0f ? 1.0507009873554805f : aa + 1.0507009873554805f * 1.6732632423543772f;
+    case GNN_ACT_ELU: return aa > 0.0f ? 1.0f : aa + 1.0f;
+    case GNN_ACT_TANH: return 1.0f - aa * aa;
+    case GNN_ACT_SIGMOID: return aa * (1.0f - aa);
+    default: return 1.0f;
+    }
+}
+
+__device__ __forceinline__ float dropout_grad(float d, uint8_t keep, float rate)
+{
+    if (rate < 0.0f) {
+        float a, b, ap;
+        alpha_dropout_coeffs(-rate, &a, &b, &ap);
+        return keep ? d * a : 0.0f;
+    }
+    return keep ? d / (1.0f - rate) : 0.0f;
+}
+
+// dz = da * act'(z) (softmax: a * (da - sum da a) per row); in place on d
 __global__ void k_act_bwd(int64_t n, int F, float *d, const float *a, int act)
 {
     if (act == GNN_ACT_SOFTMAX) {
@@ -110,23 +133,15 @@ __global__ void k_act_bwd(int64_t n, int F, float *d, const float *a, int act)
     }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * F) return;
-    const float aa = a[i];
-    float g;
-    switch (act) {
-    case GNN_ACT_RELU: g = aa > 0.0f ? 1.0f : 0.0f; break;
-    case GNN_ACT_SELU: g = aa > 0.0f ? 1.0507009873554805f : aa + 1.0507009873554805f * 1.6732632423543772f; break;
-    case GNN_ACT_ELU: g = aa > 0.0f ? 1.0f : aa + 1.0f; break;
-    case GNN_ACT_TANH: g = 1.0f - aa * aa; break;
-    case GNN_ACT_SIGMOID: g = aa * (1.0f - aa); break;
-    default: g = 1.0f; break;
-    }
-    d[i] = d[i] * g;
+    d[i] = d[i] * act_grad(a[i], act);
 }
 
-// column reductions over n rows of [n, F] matrices; one block of 256 threads = 32 columns x 8 row lanes
-// mode 0: out0[j] += sum x        mode 1: out0[j] += sum (x - aux0[j])^2        mode 2: out0[j] += sum x * y, out1[j] += sum x
-__global__ void k_colreduce(int64_t n, int F, const float *x, const float *y, const float *aux0, int mode, float *out0, float *out1,
-                            int64_t rows_per_block)
+// Row chunks.  Every reduction over the rows of a matrix (BatchNormalization statistics, bias / weight / gamma / beta gradients)
+// is done per chunk of rows_per_block(n) rows; a chunk leaves a partial result and the partials are added in chunk order
+// (k_sum_parts, or by the consumer itself): run-to-run identical sums without float atomics.
+
+// partial sums of d * xhat and d over the rows of chunk blockIdx.y: out0 / out1 [chunk * ostride + j]; 256 threads = 32 columns x 8 row lanes
+__global__ void k_colreduce2(int64_t n, int F, const float *x, const float *y, float *out0, float *out1, int64_t ostride, int64_t rows_per_block)
 {
     __shared__ float s0[8][33], s1[8][33];
     const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -136,17 +151,15 @@ __global__ void k_colreduce(int64_t n, int F, const float *x, const float *y, co
     if (j < F)
         for (int64_t r = r0 + ry; r < r1; r += 8) {
             const float v = x[r * F + j];
-            if (mode == 0) a0 += v;
-            else if (mode == 1) { const float dv = v - aux0[j]; a0 += dv * dv; }
-            else { a0 += v * y[r * F + j]; a1 += v; }
+            a0 += v * y[r * F + j];
+            a1 += v;
         }
     s0[ry][c] = a0; s1[ry][c] = a1;
     __syncthreads();
     if (ry == 0 && j < F) {
         for (int t = 1; t < 8; ++t) { a0 += s0[t][c]; a1 += s1[t][c]; }
-        // partial of this row chunk; k_sum_parts adds the chunks in a fixed order (run-to-run identical sums, no float atomics)
-        out0[(size_t)blockIdx.y * F + j] = a0;
-        if (mode == 2) out1[(size_t)blockIdx.y * F + j] = a1;
+        out0[(size_t)blockIdx.y * ostride + j] = a0;
+        out1[(size_t)blockIdx.y * ostride + j] = a1;
     }
 }
 
@@ -160,54 +173,222 @@ __global__ void k_sum_parts(int parts, int64_t count, const float *part, float *
     out[t] += acc;
 }
 
-__global__ void k_scale_vec(int n, float *v, float s)
+// BatchNormalization, training mode, forward statistics of one row chunk: part[chunk][j] = chunk mean, part[chunk][F + j] =
+// sum over the chunk of (x - chunk mean)^2 (two passes over the chunk's rows)
+__global__ void k_bn_stats(int64_t n, int F, const float *h, float *part, int64_t rows_per_block)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = v[i] * s;
+    __shared__ float s0[8][33];
+    __shared__ float mu[32];
+    const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    float a0 = 0.0f;
+    if (j < F) for (int64_t r = r0 + ry; r < r1; r += 8) a0 += h[r * F + j];
+    s0[ry][c] = a0;
+    __syncthreads();
+    if (ry == 0) {
+        for (int t = 1; t < 8; ++t) a0 += s0[t][c];
+        mu[c] = a0 / (float)(r1 - r0);
+    }
+    __syncthreads();
+    const float m = mu[c];
+    a0 = 0.0f;
+    if (j < F) for (int64_t r = r0 + ry; r < r1; r += 8) { const float dv = h[r * F + j] - m; a0 += dv * dv; }
+    __syncthreads();
+    s0[ry][c] = a0;
+    __syncthreads();
+    if (ry == 0 && j < F) {
+        for (int t = 1; t < 8; ++t) a0 += s0[t][c];
+        part[(size_t)blockIdx.y * 2 * F + j] = m;
+        part[(size_t)blockIdx.y * 2 * F + F + j] = a0;
+    }
 }
 
-__global__ void k_bn_fwd(int64_t n, int F, const float *h, const float *mean, const float *sqsum, float eps, const float *gamma,
-                         const float *beta, float *xhat, float *y, float *stats /* [2][F]: batch mean, biased batch var */)
+// batch mean / biased batch variance from the chunk statistics (pairwise update in chunk order), then xhat = (h - mean) / sqrt(var + eps),
+// y = gamma xhat + beta.  Every block combines the (few) chunks itself; block 0 leaves [mean | var] in stats for the
+// backward pass and the moving statistics.  Dynamic LDS: 2 F floats.
+__global__ void k_bn_apply(int64_t n, int F, const float *h, const float *part, int parts, int64_t rows_per_block, float eps,
+                           const float *gamma, const float *beta, float *xhat, float *y, float *stats)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * F) return;
-    const int j = (int)(i % F);
-    const float mu = mean[j], var = sqsum[j] / (float)n;
-    const float xh = (h[i] - mu) / sqrtf(var + eps);
-    xhat[i] = xh;
-    y[i] = gamma[j] * xh + beta[j];
-    if (i < F) { stats[j] = mu; stats[F + j] = var; }
+    extern __shared__ float bsh[];
+    float *sm = bsh, *sinv = bsh + F;
+    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+        float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
+        for (int z = 0; z < parts; ++z) {
+            const int64_t r0 = (int64_t)z * rows_per_block;
+            const float nz = (float)((r0 + rows_per_block < n ? r0 + rows_per_block : n) - r0);
+            const float mz = part[(size_t)z * 2 * F + j], qz = part[(size_t)z * 2 * F + F + j];
+            const float delta = mz - mean, tot = cnt + nz;
+            mean = mean + delta * (nz / tot);
+            m2 = m2 + qz + delta * delta * (cnt * nz / tot);
+            cnt = tot;
+        }
+        const float var = m2 / (float)n;
+        sm[j] = mean;
+        sinv[j] = 1.0f / sqrtf(var + eps);
+        if (blockIdx.x == 0) { stats[j] = mean; stats[F + j] = var; }
+    }
+    __syncthreads();
+    const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int j = (int)(i % F);
+        const float xh = (h[i] - sm[j]) * sinv[j];
+        xhat[i] = xh;
+        y[i] = gamma[j] * xh + beta[j];
+    }
 }
 
-// d x = inv / n * (n * dxh - sum dxh - xhat * sum(dxh * xhat)), dxh = d y * gamma; sums: s_dyx = sum dy*xhat, s_dy = sum dy
-__global__ void k_bn_bwd(int64_t n, int F, float *d, const float *xhat, const float *gamma, const float *stats, float eps,
-                         const float *s_dyx, const float *s_dy)
+// d x = inv / n * (n * dxh - sum dxh - xhat * sum(dxh * xhat)), dxh = d y * gamma, with sum d y * xhat / sum d y added up from the
+// chunk partials p_dyx / p_dy [chunk * pstride + j] (the same numbers k_sum_parts adds into the gamma / beta gradients);
+// then, fused, the derivative of the layer's activation: d <- d x * act'(a) (act < 0: none).  Dynamic LDS: 2 F floats.
+__global__ void k_bn_bwd_apply(int64_t n, int F, float *d, const float *xhat, const float *gamma, const float *stats, float eps,
+                               const float *p_dyx, const float *p_dy, int64_t pstride, int parts, const float *a, int act)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * F) return;
-    const int j = (int)(i % F);
-    const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j], m = (float)n;
-    d[i] = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
+    extern __shared__ float bsh[];
+    float *s_dyx = bsh, *s_dy = bsh + F;
+    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+        float a0 = 0.0f, a1 = 0.0f;
+        for (int z = 0; z < parts; ++z) { a0 += p_dyx[(size_t)z * pstride + j]; a1 += p_dy[(size_t)z * pstride + j]; }
+        s_dyx[j] = a0; s_dy[j] = a1;
+    }
+    __syncthreads();
+    const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
+    const float m = (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int j = (int)(i % F);
+        const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j];
+        float v = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
+        if (act >= 0) v = v * act_grad(a[i], act);
+        d[i] = v;
+    }
 }
 
-// dW[i, j] += sum_r H[r, i] * DZ[r, j] over the rows of this block's chunk; 16 x 16 output tile per block
-__global__ void k_wgrad(int64_t n, int n_in, int n_out, const float *H, const float *DZ, float *dW, int64_t rows_per_block)
+// Weight and bias gradient of one Dense layer over row chunk blockIdx.z: part[chunk * pstride + i * n_out + j] = sum_r H'[r, i] DZ[r, j]
+// with H' = [H | 1] (row i = n_in is the bias gradient: dW and db are adjacent in the gradient vector).  16 x 16 outputs per
+// block, 64 rows staged per step.
+__global__ void __launch_bounds__(256) k_wgrad(int64_t n, int n_in, int n_out, const float *H, const float *DZ, float *part, int64_t pstride,
+                                               int64_t rows_per_block)
 {
-    __shared__ float sh[16][17], sz[16][17];
+    __shared__ float sh[64][17], sz[64][17];
     const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
     const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
     const int64_t r0 = (int64_t)blockIdx.z * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     float acc = 0.0f;
-    for (int64_t r = r0; r < r1; r += 16) {
-        // tile rows r..r+15: thread (ti, tj) loads H[r + ti][i0 + tj] and DZ[r + ti][j0 + tj]
-        sh[ti][tj] = (r + ti < r1 && i0 + tj < n_in) ? H[(r + ti) * n_in + i0 + tj] : 0.0f;
-        sz[ti][tj] = (r + ti < r1 && j0 + tj < n_out) ? DZ[(r + ti) * n_out + j0 + tj] : 0.0f;
-        __syncthreads();
+    for (int64_t r = r0; r < r1; r += 64) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc += sh[q][ti] * sz[q][tj];
+        for (int q = 0; q < 4; ++q) {
+            const int64_t row = r + ti + 16 * q;
+            const bool in = row < r1;
+            sh[ti + 16 * q][tj] = !in ? 0.0f : (i0 + tj < n_in ? H[row * n_in + i0 + tj] : (i0 + tj == n_in ? 1.0f : 0.0f));
+            sz[ti + 16 * q][tj] = (in && j0 + tj < n_out) ? DZ[row * n_out + j0 + tj] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(sh[q][ti], sz[q][tj], acc);
         __syncthreads();
     }
-    if (i0 + ti < n_in && j0 + tj < n_out) dW[(size_t)blockIdx.z * n_in * n_out + (size_t)(i0 + ti) * n_out + j0 + tj] = acc;   // partial of chunk z
+    if (i0 + ti <= n_in && j0 + tj < n_out) part[(size_t)blockIdx.z * pstride + (size_t)(i0 + ti) * n_out + j0 + tj] = acc;
+}
+
+// d h_in = d z . W^T, then (fused) the way back through what produced h_in: Dropout (keep != NULL) and the previous layer's
+// activation (act >= 0: d <- d * act'(a_prev)).  R rows of d z staged in LDS, one thread per column of h_in, as k_dense.
+template <int R>
+__global__ void __launch_bounds__(256) k_dense_bwd(int64_t n, int n_out, int n_out_pad, int n_in, const float *__restrict__ DZ,
+                                                   const float *__restrict__ WT, const uint8_t *__restrict__ keep, float rate,
+                                                   const float *__restrict__ a_prev, int act, float *__restrict__ dprev)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int64_t i0 = (int64_t)blockIdx.x * R;
+    for (int t = threadIdx.x; t < R * n_out_pad; t += blockDim.x) {
+        const int r = t / n_out_pad, k = t - r * n_out_pad;
+        xs[t] = (k < n_out && i0 + r < n) ? DZ[(i0 + r) * n_out + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n_in; j += blockDim.x) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+        int k = 0;
+        for (; k + 4 <= n_out; k += 4) {
+            const float w0 = WT[(size_t)(k + 0) * n_in + j], w1 = WT[(size_t)(k + 1) * n_in + j];
+            const float w2 = WT[(size_t)(k + 2) * n_in + j], w3 = WT[(size_t)(k + 3) * n_in + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 x = *reinterpret_cast<const float4 *>(&xs[r * n_out_pad + k]);
+                acc[r] = __builtin_fmaf(x.x, w0, acc[r]);
+                acc[r] = __builtin_fmaf(x.y, w1, acc[r]);
+                acc[r] = __builtin_fmaf(x.z, w2, acc[r]);
+                acc[r] = __builtin_fmaf(x.w, w3, acc[r]);
+            }
+        }
+        for (; k < n_out; ++k) {
+            const float wk = WT[(size_t)k * n_in + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(xs[r * n_out_pad + k], wk, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (i0 + r >= n) break;
+            const int64_t o = (i0 + r) * n_in + j;
+            float v = acc[r];
+            if (keep) v = dropout_grad(v, keep[o], rate);
+            if (act >= 0) v = v * act_grad(a_prev[o], act);
+            dprev[o] = v;
+        }
+    }
+}
+
+// The concat of one body (reference GNN/GNN.py:223-239) in one pass: [state | node labels | aggregated states | aggregated labels |
+// aggregated arc labels].  Everything but the state columns and their aggregate is loop-invariant and comes from the template.
+// Dropout in front of the first Dense layer (rate != 0) is applied on the way out.
+__global__ void k_train_input(int64_t n, int in_s, int Ds, int c_aggs, const float *__restrict__ tmpl, const float *__restrict__ state,
+                              const int32_t *__restrict__ indptr, const int32_t *__restrict__ adj_src, const float *__restrict__ adj_w,
+                              float rate, const uint8_t *mask_in, uint64_t seed, uint8_t *keep, float *__restrict__ inp)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * in_s) return;
+    const int64_t r = i / in_s;
+    const int c = (int)(i - r * in_s);
+    float v;
+    if (c < Ds) v = state[r * Ds + c];
+    else if (c >= c_aggs && c < c_aggs + Ds) {
+        const int cc = c - c_aggs;
+        v = 0.0f;
+        for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) v = __builtin_fmaf(adj_w[e], state[(int64_t)adj_src[e] * Ds + cc], v);
+    } else
+        v = tmpl[i];
+    if (rate != 0.0f) {
+        const float rr = fabsf(rate);
+        uint8_t kp;
+        if (mask_in) kp = mask_in[i] != 0;
+        else kp = ((mix64(seed ^ mix64((uint64_t)i)) >> 40) * (1.0f / 16777216.0f)) >= rr;
+        keep[i] = kp;
+        if (rate < 0.0f) {
+            float a, b, ap;
+            alpha_dropout_coeffs(rr, &a, &b, &ap);
+            v = a * (kp ? v : ap) + b;
+        } else
+            v = kp ? v / (1.0f - rate) : 0.0f;
+    }
+    inp[i] = v;
+}
+
+// condition() of the training-mode loop (reference GNN/GNN.py:202-220), one thread per node, ascending-feature sums as k_check
+__global__ void k_train_check(int64_t n, int d, const float *s, const float *so, float thr, int *flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int f = 0;
+    if (i < n) {
+        float dist = 0.0f, nrm = 0.0f;
+        for (int c = 0; c < d; ++c) {
+            const float o = so ? so[i * d + c] : 1.0f;
+            const float df = s[i * d + c] - o;
+            dist = dist + df * df;
+            nrm = nrm + o * o;
+        }
+        f = __fsqrt_rn(dist) > thr * __fsqrt_rn(nrm);
+    }
+    if (__any(f) && (threadIdx.x & 63) == 0) gnn_flag_raise(flag);
 }
 
 __global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
@@ -230,14 +411,18 @@ __global__ void k_scatter_rows(int64_t m, const int32_t *rows, const float *d_fe
     d_state[(int64_t)rows[q] * Ds + c] = d_feats[q * wf + c];
 }
 
-// d_state[r, c] = d_inp[r, c] + tmp[r, c]   (own-state columns of the concat + transposed aggregation)
-__global__ void k_combine(int64_t n, int Ds, const float *d_inp, int in_s, const float *tmp, float *d_state)
+// aggregated_states = Adjacency^T . state  =>  d state[r] = d inp[r, :Ds] + sum over arcs (r -> dst) of w * d inp[dst, c_aggs:]:
+// own-state columns of the concat + the transposed aggregation over the by-source CSR, in one pass
+__global__ void k_state_grad(int64_t n, int Ds, int in_s, int c_aggs, const float *__restrict__ d_inp, const int32_t *__restrict__ sip,
+                             const int32_t *__restrict__ sdst, const float *__restrict__ sw, float *__restrict__ d_state)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * Ds) return;
     const int64_t r = t / Ds;
     const int c = (int)(t - r * Ds);
-    d_state[t] = d_inp[r * in_s + c] + tmp[t];
+    float acc = 0.0f;
+    for (int32_t e = sip[r]; e < sip[r + 1]; ++e) acc = __builtin_fmaf(sw[e], d_inp[(int64_t)sdst[e] * in_s + c_aggs + c], acc);
+    d_state[t] = d_inp[r * in_s + c] + acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -264,7 +449,24 @@ struct TrainArena {
         off = bytes;
         return s.p;
     }
-    ~TrainArena() { for (Slab &s : slabs) (void)hipFree(s.p); }
+    // pinned host words for the results the host waits for (iteration gates, loss partials)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    void *host(size_t bytes)
+    {
+        if (bytes > pinned_bytes) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr; pinned_bytes = 0;
+            if (hipHostMalloc(&pinned, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+            pinned_bytes = bytes;
+        }
+        return pinned;
+    }
+    ~TrainArena()
+    {
+        for (Slab &s : slabs) (void)hipFree(s.p);
+        if (pinned) (void)hipHostFree(pinned);
+    }
 };
 
 struct Buf {                      // typed front end of the arena
@@ -277,38 +479,6 @@ struct Buf {                      // typed front end of the arena
         return GNN_OK;
     }
 };
-
-// out0[j] (+ out1[j]) += column reduction of k_colreduce over all n rows, deterministic: partials per row chunk, then k_sum_parts
-static int reduce_cols(hipStream_t st, Buf &buf, int64_t n, int F, const float *x, const float *y, const float *aux0, int mode, float *out0, float *out1)
-{
-    if (n <= 0 || F <= 0) return GNN_OK;
-    const int64_t rpb = rows_per_block(n);
-    const int parts = (int)cdiv(n, rpb);
-    float *p0 = nullptr, *p1 = nullptr;
-    int rc = buf.get(&p0, (size_t)parts * F);
-    if (!rc && mode == 2) rc = buf.get(&p1, (size_t)parts * F);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_colreduce, dim3(cdiv(F, 32), parts), 256, 0, st, n, F, x, y, aux0, mode, p0, p1, rpb);
-    hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, parts, (int64_t)F, p0, out0);
-    if (mode == 2) hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, parts, (int64_t)F, p1, out1);
-    HIPCHK(hipGetLastError());
-    return GNN_OK;
-}
-
-// dW += H^T . DZ, deterministic in the same way
-static int weight_grad(hipStream_t st, Buf &buf, int64_t n, int ni, int no, const float *H, const float *DZ, float *dW)
-{
-    if (n <= 0) return GNN_OK;
-    const int64_t rpb = rows_per_block(n);
-    const int parts = (int)cdiv(n, rpb);
-    float *part = nullptr;
-    int rc = buf.get(&part, (size_t)parts * ni * no);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_wgrad, dim3(cdiv(ni, 16), cdiv(no, 16), parts), 256, 0, st, n, ni, no, H, DZ, part, rpb);
-    hipLaunchKernelGGL(k_sum_parts, cdiv((int64_t)ni * no, 256), 256, 0, st, parts, (int64_t)ni * no, part, dW);
-    HIPCHK(hipGetLastError());
-    return GNN_OK;
-}
 
 __global__ void k_transpose(int ni, int no, const float *W, float *WT)
 {
@@ -330,11 +500,14 @@ struct Net {
     std::vector<float *> WT;      // W^T per layer
     float *gamma = nullptr, *beta = nullptr;
     std::vector<float> rate;      // [L + 1] dropout rate in front of Dense l (index L: in front of BatchNormalization)
-    float *zero = nullptr;        // zero "bias" of the d h = d z . W^T products (max layer input width)
     float *grads = nullptr;       // flat: dW1, db1, ..., dgamma, dbeta
     std::vector<size_t> g_off;
     size_t g_total = 0;
+    float *part = nullptr;        // [chunks of the rows][g_total]: the partial gradients of ONE net_backward call
+    int64_t part_rows = -1;
 };
+
+inline unsigned elementwise_grid(int64_t total) { return (unsigned)std::min<int64_t>(std::max<int64_t>(1, (total + 255) / 256), 2048); }
 
 int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host)
 {
@@ -362,17 +535,16 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
         net.g_off.push_back(off); off += F;
     }
     net.g_total = off;
-    int maxw = 1;
-    for (int l = 0; l <= L; ++l) maxw = std::max(maxw, m->dims[l]);
-    int rc = buf.get(&net.grads, off + maxw);         // gradients, then the zero vector: one memset
+    int rc = buf.get(&net.grads, off);
     if (rc) return rc;
-    net.zero = net.grads + off;
-    HIPCHK(hipMemsetAsync(net.grads, 0, (off + maxw) * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(net.grads, 0, std::max<size_t>(off, 1) * sizeof(float), st));
     return GNN_OK;
 }
 
-// training-mode forward of one Sequential on n rows (x: [n, dims[0]]); *y_out: [n, dims.back()]
-int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, const uint8_t *masks, uint64_t seed, NetCache &c, float **y_out)
+// training-mode forward of one Sequential on n rows (x: [n, dims[0]]); *y_out: [n, dims.back()].  keep0 != NULL: the Dropout
+// in front of the first Dense layer has been applied by the producer of x (k_train_input), its mask is keep0.
+int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, uint8_t *keep0, const uint8_t *masks, uint64_t seed, NetCache &c,
+                float **y_out)
 {
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
@@ -384,15 +556,18 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
     for (int l = 0; l <= L; ++l) {
         const int width = m->dims[l];
         if (net.rate[l] != 0.0f) {
-            float *hd = nullptr;
-            if ((rc = buf.get(&hd, (size_t)n * width)) || (rc = buf.get(&c.keep[l], (size_t)n * width))) return rc;
-            if (n > 0) {
-                hipLaunchKernelGGL(k_dropout_fwd, cdiv(n * width, 256), 256, 0, st, n * width, h, masks ? masks + mask_off : nullptr, net.rate[l],
-                                   seed + 0x9E37ull * (uint64_t)(l + 1), c.keep[l], hd);
-                HIPCHK(hipGetLastError());
+            if (l == 0 && keep0) c.keep[0] = keep0;
+            else {
+                float *hd = nullptr;
+                if ((rc = buf.get(&hd, (size_t)n * width)) || (rc = buf.get(&c.keep[l], (size_t)n * width))) return rc;
+                if (n > 0) {
+                    hipLaunchKernelGGL(k_dropout_fwd, cdiv(n * width, 256), 256, 0, st, n * width, h, masks ? masks + mask_off : nullptr, net.rate[l],
+                                       seed + 0x9E37ull * (uint64_t)(l + 1), c.keep[l], hd);
+                    HIPCHK(hipGetLastError());
+                }
+                h = hd;
             }
             mask_off += (size_t)n * width;
-            h = hd;
         }
         if (l == L) break;
         const int no = m->dims[l + 1];
@@ -408,16 +583,17 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
     }
     if (m->has_bn) {
         const int F = m->dims.back();
-        float *sums = nullptr, *y = nullptr;
-        if ((rc = buf.get(&sums, (size_t)2 * F)) || (rc = buf.get(&c.xhat, (size_t)n * F)) || (rc = buf.get(&c.stats, (size_t)2 * F)) ||
-            (rc = buf.get(&y, (size_t)n * F))) return rc;
-        HIPCHK(hipMemsetAsync(sums, 0, sizeof(float) * 2 * F, st));
+        float *y = nullptr;
+        if ((rc = buf.get(&c.xhat, (size_t)n * F)) || (rc = buf.get(&c.stats, (size_t)2 * F)) || (rc = buf.get(&y, (size_t)n * F))) return rc;
         HIPCHK(hipMemsetAsync(c.stats, 0, sizeof(float) * 2 * F, st));
         if (n > 0) {
-            if ((rc = reduce_cols(st, buf, n, F, h, nullptr, nullptr, 0, sums, nullptr))) return rc;
-            hipLaunchKernelGGL(k_scale_vec, cdiv(F, 64), 64, 0, st, F, sums, 1.0f / (float)n);                       // sums -> batch mean
-            if ((rc = reduce_cols(st, buf, n, F, h, nullptr, sums, 1, sums + F, nullptr))) return rc;
-            hipLaunchKernelGGL(k_bn_fwd, cdiv(n * F, 256), 256, 0, st, n, F, h, sums, sums + F, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
+            const int64_t rpb = rows_per_block(n);
+            const int parts = (int)cdiv(n, rpb);
+            float *part = nullptr;
+            if ((rc = buf.get(&part, (size_t)parts * 2 * F))) return rc;
+            hipLaunchKernelGGL(k_bn_stats, dim3(cdiv(F, 32), parts), 256, 0, st, n, F, h, part, rpb);
+            hipLaunchKernelGGL(k_bn_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, h, part, parts, rpb, m->eps, net.gamma,
+                               net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
         }
         h = y;
@@ -427,50 +603,72 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, c
 }
 
 // back-propagation through one Sequential: d is d loss / d y on entry ([n, dims.back()], overwritten); on return *dx_out is
-// d loss / d x ([n, dims[0]]); weight gradients are ADDED into net.grads
+// d loss / d x ([n, dims[0]]); weight gradients are ADDED into net.grads (one k_sum_parts over the call's chunk partials)
 int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d, float **dx_out)
 {
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
     const int64_t n = c.n;
     int rc;
-    if (m->has_bn && n > 0) {
-        const int F = m->dims.back();
-        float *dgamma = net.grads + net.g_off[2 * L], *dbeta = net.grads + net.g_off[2 * L + 1];
-        float *loc = nullptr;                      // this call's own column sums (the grads accumulate over iterations)
-        if ((rc = buf.get(&loc, (size_t)2 * F))) return rc;
-        HIPCHK(hipMemsetAsync(loc, 0, sizeof(float) * 2 * F, st));
-        if ((rc = reduce_cols(st, buf, n, F, d, c.xhat, nullptr, 2, loc, loc + F))) return rc;
-        hipLaunchKernelGGL(k_bn_bwd, cdiv(n * F, 256), 256, 0, st, n, F, d, c.xhat, net.gamma, c.stats, m->eps, loc, loc + F);
-        // dgamma += loc[0:F], dbeta += loc[F:2F]
-        hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, 1, (int64_t)F, loc, dgamma);
-        hipLaunchKernelGGL(k_sum_parts, cdiv(F, 64), 64, 0, st, 1, (int64_t)F, loc + F, dbeta);
-        HIPCHK(hipGetLastError());
+    if (n <= 0) {                              // no rows: no gradient; d x is empty
+        *dx_out = d;
+        return GNN_OK;
     }
-    if (net.rate[L] != 0.0f && n > 0) {
+    const int64_t rpb = rows_per_block(n);
+    const int parts = (int)cdiv(n, rpb);
+    if (net.part_rows != n) {
+        if ((rc = buf.get(&net.part, (size_t)parts * net.g_total))) return rc;
+        net.part_rows = n;
+    }
+    const int64_t ps = (int64_t)net.g_total;
+    const int act_last = m->acts[L - 1];
+    // the derivative of the last activation rides on the BatchNormalization pass when nothing sits between them
+    bool last_act_done = false;
+    if (m->has_bn) {
+        const int F = m->dims.back();
+        float *p_dyx = net.part + net.g_off[2 * L], *p_dy = net.part + net.g_off[2 * L + 1];
+        const bool fuse = net.rate[L] == 0.0f && act_last != GNN_ACT_SOFTMAX;
+        hipLaunchKernelGGL(k_colreduce2, dim3(cdiv(F, 32), parts), 256, 0, st, n, F, d, c.xhat, p_dyx, p_dy, ps, rpb);
+        hipLaunchKernelGGL(k_bn_bwd_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, d, c.xhat, net.gamma, c.stats, m->eps,
+                           p_dyx, p_dy, ps, parts, c.a[L - 1], fuse ? act_last : -1);
+        HIPCHK(hipGetLastError());
+        last_act_done = fuse;
+    }
+    if (net.rate[L] != 0.0f) {
         const int F = m->dims.back();
         hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * F, 256), 256, 0, st, n * F, c.keep[L], net.rate[L], d);
         HIPCHK(hipGetLastError());
     }
+    if (!last_act_done) {
+        const int no = m->dims[L];
+        const bool sm = act_last == GNN_ACT_SOFTMAX;
+        if (sm || act_last != GNN_ACT_LINEAR) {
+            hipLaunchKernelGGL(k_act_bwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, d, c.a[L - 1], act_last);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    // d is d loss / d z of layer l at the top of every pass
     for (int l = L - 1; l >= 0; --l) {
         const int ni = m->dims[l], no = m->dims[l + 1];
         float *dprev = nullptr;
         if ((rc = buf.get(&dprev, (size_t)n * ni))) return rc;
-        if (n > 0) {
-            const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;
-            hipLaunchKernelGGL(k_act_bwd, cdiv(sm ? n : n * no, 256), 256, 0, st, n, no, d, c.a[l], m->acts[l]);
-            HIPCHK(hipGetLastError());
-            if ((rc = weight_grad(st, buf, n, ni, no, c.hin[l], d, net.grads + net.g_off[2 * l]))) return rc;
-            if ((rc = reduce_cols(st, buf, n, no, d, nullptr, nullptr, 0, net.grads + net.g_off[2 * l + 1], nullptr))) return rc;
-        }
-        // d h_in = d z . W^T  (bias-free: the zero vector behind the gradients)
-        if ((rc = gnn_launch_dense(st, n, no, ni, d, no, net.WT[l], net.zero, GNN_ACT_LINEAR, dprev, ni))) return rc;
-        if (net.rate[l] != 0.0f && n > 0) {
-            hipLaunchKernelGGL(k_dropout_bwd, cdiv(n * ni, 256), 256, 0, st, n * ni, c.keep[l], net.rate[l], dprev);
-            HIPCHK(hipGetLastError());
-        }
+        hipLaunchKernelGGL(k_wgrad, dim3(cdiv(ni + 1, 16), cdiv(no, 16), parts), 256, 0, st, n, ni, no, c.hin[l], d, net.part + net.g_off[2 * l], ps, rpb);
+        // d h_in = d z . W^T, back through Dropout l and (l > 0) the activation of layer l - 1
+        const int act_prev = l > 0 ? m->acts[l - 1] : -1;
+        const bool prev_sm = act_prev == GNN_ACT_SOFTMAX;
+        constexpr int R = 8;
+        const int no_pad = (no + 3) & ~3;
+        const size_t lds = sizeof(float) * R * no_pad;
+        if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer width %d too large", no);
+        hipLaunchKernelGGL((k_dense_bwd<R>), cdiv(n, R), std::min(256, ((ni + 63) / 64) * 64), lds, st, n, no, no_pad, ni, d, net.WT[l],
+                           net.rate[l] != 0.0f ? c.keep[l] : (const uint8_t *)nullptr, net.rate[l], l > 0 ? c.a[l - 1] : (const float *)nullptr,
+                           prev_sm ? -1 : act_prev, dprev);
+        if (prev_sm) hipLaunchKernelGGL(k_act_bwd, cdiv(n, 256), 256, 0, st, n, ni, dprev, c.a[l - 1], act_prev);
+        HIPCHK(hipGetLastError());
         d = dprev;
     }
+    hipLaunchKernelGGL(k_sum_parts, cdiv((int64_t)net.g_total, 256), 256, 0, st, parts, (int64_t)net.g_total, net.part, net.grads);
+    HIPCHK(hipGetLastError());
     *dx_out = d;
     return GNN_OK;
 }
@@ -514,6 +712,78 @@ void loss_host(int kind, int64_t n, int T, const float *t, const float *o, const
         }
     }
     *loss = total;
+}
+
+// The same on the device, one thread per target row: d_o [n, T] and, per block of 256 rows, the sum of w_i L_i (fixed tree, double)
+__global__ void __launch_bounds__(256) k_loss_rows(int kind, int64_t n, int T, const float *t, const float *o, const float *w, float *d_o, double *loss_part)
+{
+    __shared__ double sl[256];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double lw = 0.0;
+    if (i < n) {
+        const float *ti = t + i * T, *oi = o + i * T;
+        const double wi = w[i];
+        if (kind == 0) {
+            double s = 0.0;
+            for (int j = 0; j < T; ++j) s += oi[j];
+            double li = 0.0, gp = 0.0;
+            for (int j = 0; j < T; ++j) {
+                const double pj = oi[j] / s;
+                const bool in = pj >= 1e-7 && pj <= 1.0 - 1e-7;
+                const double pc = fmin(fmax(pj, 1e-7), 1.0 - 1e-7);
+                li -= ti[j] * log(pc);
+                gp += (in ? -ti[j] / pc : 0.0) * pj;
+            }
+            for (int j = 0; j < T; ++j) {
+                const double pj = oi[j] / s;
+                const bool in = pj >= 1e-7 && pj <= 1.0 - 1e-7;
+                const double pc = fmin(fmax(pj, 1e-7), 1.0 - 1e-7);
+                d_o[i * T + j] = (float)(wi * ((in ? -ti[j] / pc : 0.0) - gp) / s);
+            }
+            lw = wi * li;
+        } else if (kind == 2) {
+            double mx = oi[0], s = 0.0, st = 0.0, li = 0.0;
+            for (int j = 1; j < T; ++j) mx = fmax(mx, (double)oi[j]);
+            for (int j = 0; j < T; ++j) { s += exp(oi[j] - mx); st += ti[j]; }
+            for (int j = 0; j < T; ++j) {
+                const double logp = (oi[j] - mx) - log(s);
+                li -= ti[j] * logp;
+                d_o[i * T + j] = (float)(wi * (exp(logp) * st - ti[j]));
+            }
+            lw = wi * li;
+        } else {
+            double li = 0.0;
+            for (int j = 0; j < T; ++j) { const double e = (double)oi[j] - ti[j]; li += e * e; d_o[i * T + j] = (float)(wi * 2.0 * e / T); }
+            lw = wi * li / T;
+        }
+    }
+    sl[threadIdx.x] = lw;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sl[threadIdx.x] += sl[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = sl[0];
+}
+
+// GNNgraphBased readout inside the step: og = NodeGraph^T . out_nodes (GNN.py:331-332) over the CSR by graph, and its transpose
+__global__ void k_graph_out(int n_graphs, int T, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w, const float *out_nodes, float *og)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_graphs * T) return;
+    const int gi = t / T, c = t - gi * T;
+    float acc = 0.0f;
+    for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e) acc += ng_w[e] * out_nodes[(int64_t)ng_node[e] * T + c];
+    og[t] = acc;
+}
+
+__global__ void k_graph_out_bwd(int n_graphs, int T, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w, const float *d_og, float *d_nodes)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_graphs * T) return;
+    const int gi = t / T, c = t - gi * T;
+    // a node belongs to one graph: the adds of different threads do not meet (atomic only so that a malformed NodeGraph stays defined)
+    for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e) atomicAdd(&d_nodes[(int64_t)ng_node[e] * T + c], ng_w[e] * d_og[t]);
 }
 
 // d_nodes[r, c] += d_inp[r, c_nodes + c] + via[r, c]   (direct label columns of the concat + transposed aggregated_nodes)
@@ -599,7 +869,10 @@ struct TrainCtx {
     float *d_sw = nullptr;
     float *state = nullptr, *out_nodes = nullptr;
     int k = 0;
+    int64_t N = 0, M = 0;
 };
+
+constexpr int TRAIN_CHUNK = 5;     // bodies enqueued between two looks at the iteration gates (see train_forward)
 
 }   // namespace
 
@@ -630,10 +903,11 @@ extern "C" int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const flo
     return GNN_OK;
 }
 
-extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
-                                      const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
-                                      const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
-                                      float *k_out, float *out_nodes_host)
+
+// Training-mode Loop.  final_sync: wait for the published state / outputs (and out_nodes_host) before returning.
+static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w, const float *dropout_state,
+                         const float *dropout_output, const uint8_t *masks_state, const uint8_t *masks_output, uint64_t seed,
+                         const float *bn_state, const float *bn_output, float *k_out, float *out_nodes_host, bool final_sync)
 {
     ARGCHK(l && dropout_state && dropout_output && k_out, "bad arguments");
     ARGCHK(l->world == 1, "training is single-GPU");
@@ -648,10 +922,12 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     hipStream_t st = l->stream;
     gnn_train_ctx_free(l);
     if (!l->train_arena) l->train_arena = new TrainArena();
-    static_cast<TrainArena *>(l->train_arena)->reset();
+    TrainArena *arena = static_cast<TrainArena *>(l->train_arena);
+    arena->reset();
     TrainCtx *cx = new TrainCtx();
     l->train_ctx = cx;
-    cx->buf.arena = static_cast<TrainArena *>(l->train_arena);
+    cx->buf.arena = arena;
+    cx->N = N; cx->M = M;
     Buf &buf = cx->buf;
     Net &ns = cx->ns, &no_ = cx->no_;
     int rc;
@@ -687,30 +963,13 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     // template of the concat with the loop-invariant columns filled in (GNN.py:259, :263)
     float *tmpl = nullptr;
     if ((rc = buf.get(&tmpl, (size_t)N * in_s))) return rc;
-    HIPCHK(hipMemsetAsync(tmpl, 0, sizeof(float) * (size_t)N * in_s, st));
+    HIPCHK(hipMemsetAsync(tmpl, 0, sizeof(float) * std::max<size_t>(1, (size_t)N * in_s), st));
     const int c_nodes = Ds, c_aggs = Ds + NLc, c_aggn = c_aggs + Ds, c_agga = c_aggn + NLc;
     if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
     if (l->D) {
         if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, tmpl + c_aggn, in_s, nullptr, 1))) return rc;
         if ((rc = gnn_launch_copy_cols(st, N, g->NL, g->nodes, g->NL, tmpl + c_nodes, in_s, nullptr, 1))) return rc;
     }
-    // state, condition flags
-    float *state = nullptr, *state_old = nullptr;
-    int *flag = nullptr;
-    if ((rc = buf.get(&state, (size_t)N * Ds)) || (rc = buf.get(&state_old, (size_t)N * Ds)) || (rc = buf.get(&flag, (size_t)GNN_FLAG_WORDS))) return rc;
-    if (N) HIPCHK(hipMemcpyAsync(state, l->D ? l->state_init : g->nodes, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
-    std::vector<int> hflag(GNN_FLAG_WORDS);
-    auto not_converged = [&](const float *s, const float *so, bool *go) -> int {
-        HIPCHK(hipMemsetAsync(flag, 0, sizeof(int) * GNN_FLAG_WORDS, st));
-        int r = gnn_launch_check(st, N, Ds, s, so, l->thr, flag);
-        if (r) return r;
-        HIPCHK(hipMemcpyAsync(hflag.data(), flag, sizeof(int) * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        int any = 0;
-        for (int i = 0; i < GNN_FLAG_WORDS; i += GNN_FLAG_STRIDE) any |= hflag[i];
-        *go = any != 0;
-        return GNN_OK;
-    };
     // masks of one iteration of net_state: sum over the dropout positions of N * width bytes
     size_t mask_iter_bytes = 0;
     for (int i = 0; i <= l->st->n_layers; ++i) if (dropout_state[i] != 0.0f) mask_iter_bytes += (size_t)N * l->st->dims[i];
@@ -727,23 +986,54 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     }
 
     // ---- while condition: state <- net_state(concat), training mode (GNN.py:271 with training=True) ----------------------
-    bool go = false;
-    if ((rc = not_converged(state, nullptr, &go))) return rc;
-    int k = 0;
-    while (go && k < l->max_iter) {
-        float *inp = nullptr, *y = nullptr;
-        if ((rc = buf.get(&inp, (size_t)N * in_s))) return rc;
-        HIPCHK(hipMemcpyAsync(inp, tmpl, sizeof(float) * (size_t)N * in_s, hipMemcpyDeviceToDevice, st));
-        if ((rc = gnn_launch_copy_cols(st, N, Ds, state, Ds, inp, in_s, nullptr, 1))) return rc;
-        if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, state, Ds, Ds, inp + c_aggs, in_s, nullptr, 1))) return rc;
-        cx->caches.emplace_back();
-        if ((rc = net_forward(st, buf, ns, N, inp, d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)k : nullptr, seed + 7919ull * (uint64_t)(k + 1),
-                              cx->caches.back(), &y))) return rc;
-        std::swap(state, state_old);
-        if (N) HIPCHK(hipMemcpyAsync(state, y, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
-        ++k;
-        if ((rc = not_converged(state, state_old, &go))) return rc;
+    // Gate i = condition(state_i, state_{i-1}) decides whether body i runs.  The bodies are enqueued TRAIN_CHUNK at a time without
+    // waiting for their gates; the host then reads the gates of the chunk in one synchronisation, and the bodies enqueued
+    // beyond a closed gate (at most TRAIN_CHUNK - 1 of them) are dropped: their results are never read.
+    const int max_iter = l->max_iter;
+    int *flags = nullptr;
+    const size_t flag_words = (size_t)(max_iter + 1) * GNN_FLAG_WORDS;
+    if ((rc = buf.get(&flags, flag_words))) return rc;
+    HIPCHK(hipMemsetAsync(flags, 0, sizeof(int) * flag_words, st));
+    int *hflags = static_cast<int *>(arena->host(std::max<size_t>(sizeof(int) * flag_words, 4096)));
+    if (!hflags) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
+    std::vector<float *> states;                       // states[i]: the state body i reads; states[0] is read in place
+    states.push_back(const_cast<float *>(l->D ? l->state_init : g->nodes));
+    auto check = [&](int i) {
+        if (N) hipLaunchKernelGGL(k_train_check, cdiv(N, 256), 256, 0, st, N, Ds, states[i], i ? states[i - 1] : (const float *)nullptr, l->thr,
+                                  flags + (size_t)i * GNN_FLAG_WORDS);
+    };
+    check(0);
+    int enq = 0, k = -1;
+    while (k < 0) {
+        const int target = std::min(max_iter, enq + TRAIN_CHUNK);
+        for (; enq < target; ++enq) {
+            float *inp = nullptr, *y = nullptr;
+            uint8_t *keep0 = nullptr;
+            const float r0 = dropout_state[0];
+            if ((rc = buf.get(&inp, (size_t)N * in_s))) return rc;
+            if (r0 != 0.0f && (rc = buf.get(&keep0, (size_t)N * in_s))) return rc;
+            const uint8_t *mk = d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)enq : nullptr;
+            const uint64_t sd = seed + 7919ull * (uint64_t)(enq + 1);
+            if (N) hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
+                                      g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp);
+            HIPCHK(hipGetLastError());
+            cx->caches.emplace_back();
+            if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y))) return rc;
+            states.push_back(y);
+            check(enq + 1);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int) * (size_t)(enq + 1) * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int i = 0; i <= enq && k < 0; ++i) {
+            int any = 0;
+            for (int w = 0; w < GNN_FLAG_WORDS; w += GNN_FLAG_STRIDE) any |= hflags[(size_t)i * GNN_FLAG_WORDS + w];
+            if (!any) k = i;
+        }
+        if (k < 0 && enq == max_iter) k = max_iter;
     }
+    cx->caches.resize((size_t)k);
+    float *state = states[(size_t)k];
     // ---- net_output on the masked rows --------------------------------------------------------------------------------------
     float *feats = nullptr;
     if ((rc = buf.get(&feats, (size_t)M * wf))) return rc;
@@ -753,17 +1043,16 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
         hipLaunchKernelGGL(k_gather_feats, cdiv(M * wf, 256), 256, 0, st, M, g->sh->masked_rows, state, Ds, g->nodes, g->NL, NLc, feats);
         HIPCHK(hipGetLastError());
     }
-    if ((rc = net_forward(st, buf, no_, M, feats, d_masks_o, seed + 104729ull, cx->co, &cx->out_nodes))) return rc;
+    if ((rc = net_forward(st, buf, no_, M, feats, nullptr, d_masks_o, seed + 104729ull, cx->co, &cx->out_nodes))) return rc;
     cx->state = state;
     cx->k = k;
     // publish the training-mode state / outputs as the loop's result: gnn_loop_get_state / get_output / readout and
     // gnn_graph_update_labels (LGNN stacking) read them exactly like an inference run's
-    const int zero = 0;
     if (N) HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
     if (M) HIPCHK(hipMemcpyAsync(l->out, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(l->kfinal_dev, &zero, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(l->kfinal_dev, 0, sizeof(int), st));
     if (out_nodes_host && M) HIPCHK(hipMemcpyAsync(out_nodes_host, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (final_sync) HIPCHK(hipStreamSynchronize(st));
     l->kfinal = 0;
     *l->kfinal_host = 0;
     l->ran = true;
@@ -771,9 +1060,18 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
     return GNN_OK;
 }
 
-extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
-                                       float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host,
-                                       float *d_arcs_host)
+extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
+                                      const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,
+                                      const uint8_t *masks_output, uint64_t seed, const float *bn_state, const float *bn_output,
+                                      float *k_out, float *out_nodes_host)
+{
+    return train_forward(l, src_indptr, src_dst, src_w, dropout_state, dropout_output, masks_state, masks_output, seed, bn_state, bn_output, k_out,
+                         out_nodes_host, true);
+}
+
+// d_out_dev: d loss / d out_nodes already on the device (gnn_loop_train_step), else d_out_host is uploaded
+static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host, const float *d_state_extra, float *grads_state,
+                          float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host, float *d_arcs_host)
 {
     ARGCHK(l && grads_state && grads_output, "bad arguments");
     TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
@@ -781,19 +1079,19 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
     gnn_graph *g = l->g;
     const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked;
     const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->ou->dims[0], NL = g->NL, k = cx->k;
-    ARGCHK(M == 0 || d_out_nodes, "d_out_nodes is NULL");
+    ARGCHK(M == 0 || d_out_dev || d_out_host, "d_out_nodes is NULL");
     HIPCHK(hipSetDevice(l->device));
     hipStream_t st = l->stream;
     Buf &buf = cx->buf;
     Net &ns = cx->ns, &no_ = cx->no_;
     const int c_nodes = Ds, c_aggs = Ds + NLc, c_aggn = c_aggs + Ds;
     int rc;
-    float *d_out = nullptr, *d_feats = nullptr, *d_state = nullptr, *tmp = nullptr, *d_nodes = nullptr, *via = nullptr;
-    if ((rc = buf.get(&d_out, (size_t)M * T)) || (rc = buf.get(&d_state, (size_t)N * Ds)) || (rc = buf.get(&tmp, (size_t)N * Ds))) return rc;
-    if (M) HIPCHK(hipMemcpyAsync(d_out, d_out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, st));
+    float *d_out = d_out_dev, *d_feats = nullptr, *d_state = nullptr, *tmp = nullptr, *d_nodes = nullptr, *via = nullptr;
+    if ((!d_out && (rc = buf.get(&d_out, (size_t)M * T))) || (rc = buf.get(&d_state, (size_t)N * Ds))) return rc;
+    if (!d_out_dev && M) HIPCHK(hipMemcpyAsync(d_out, d_out_host, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, st));
     if ((rc = net_backward(st, buf, no_, cx->co, d_out, &d_feats))) return rc;
     if (d_state_extra) { if (N) HIPCHK(hipMemcpyAsync(d_state, d_state_extra, sizeof(float) * (size_t)N * Ds, hipMemcpyHostToDevice, st)); }
-    else HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * (size_t)N * Ds, st));
+    else HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * std::max<size_t>(1, (size_t)N * Ds), st));
     const bool want_nodes = d_nodes_host != nullptr;
     const bool want_arcs = d_arcs_host != nullptr && g->AL > 0;
     const int AL = g->AL, c_agga = c_aggn + NLc;
@@ -806,7 +1104,7 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
     }
     if (want_nodes && l->D) {
         if ((rc = buf.get(&d_nodes, (size_t)N * NL)) || (rc = buf.get(&via, (size_t)N * NL))) return rc;
-        HIPCHK(hipMemsetAsync(d_nodes, 0, sizeof(float) * (size_t)N * NL, st));
+        HIPCHK(hipMemsetAsync(d_nodes, 0, sizeof(float) * std::max<size_t>(1, (size_t)N * NL), st));
     }
     if (l->edge_mode) {
         if (M) {
@@ -817,6 +1115,7 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
         }
     } else if (M) {
         if (d_state_extra) {        // extra + scattered rows: scatter into a zero buffer, then add
+            if ((rc = buf.get(&tmp, (size_t)N * Ds))) return rc;
             HIPCHK(hipMemsetAsync(tmp, 0, sizeof(float) * (size_t)N * Ds, st));
             hipLaunchKernelGGL(k_scatter_rows, cdiv(M * Ds, 256), 256, 0, st, M, g->sh->masked_rows, d_feats, wf, Ds, tmp);
             hipLaunchKernelGGL(k_axpy1, cdiv(N * Ds, 256), 256, 0, st, N * Ds, tmp, d_state);
@@ -831,16 +1130,15 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
         }
     }
     for (int it = k - 1; it >= 0; --it) {
-        float *d_inp = nullptr, *dy = nullptr;
-        if ((rc = buf.get(&dy, (size_t)N * Ds))) return rc;                       // net_backward overwrites its input
-        if (N) HIPCHK(hipMemcpyAsync(dy, d_state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
-        if ((rc = net_backward(st, buf, ns, cx->caches[it], dy, &d_inp))) return rc;
-        // aggregated_states = Adjacency^T . state  =>  d state[src] = d inp[src, :Ds] + sum over arcs (src -> dst) of w * d agg[dst]
-        if ((rc = gnn_launch_spmm(st, N, cx->d_sip, cx->d_sdst, cx->d_sw, d_inp + c_aggs, Ds, in_s, tmp, Ds, nullptr, 1))) return rc;
+        // net_backward consumes d_state (d loss / d state_{it+1}) in place; k_state_grad then writes d loss / d state_it into a new buffer
+        float *d_inp = nullptr, *d_prev = nullptr;
+        if ((rc = net_backward(st, buf, ns, cx->caches[it], d_state, &d_inp))) return rc;
+        if ((rc = buf.get(&d_prev, (size_t)N * Ds))) return rc;
         if (N) {
-            hipLaunchKernelGGL(k_combine, cdiv(N * Ds, 256), 256, 0, st, N, Ds, d_inp, in_s, tmp, d_state);
+            hipLaunchKernelGGL(k_state_grad, cdiv(N * Ds, 256), 256, 0, st, N, Ds, in_s, c_aggs, d_inp, cx->d_sip, cx->d_sdst, cx->d_sw, d_prev);
             HIPCHK(hipGetLastError());
         }
+        d_state = d_prev;
         if (want_arcs && N) {
             hipLaunchKernelGGL(k_add_cols, cdiv(N * AL, 256), 256, 0, st, N, AL, d_inp, in_s, c_agga, d_aa);
             HIPCHK(hipGetLastError());
@@ -866,8 +1164,16 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
     if (want_nodes && N)        // D == 0: state_0 = nodes (GNN.py:265), so the gradient of the initial state IS the label gradient
         HIPCHK(hipMemcpyAsync(d_nodes_host, l->D ? d_nodes : d_state, sizeof(float) * (size_t)N * NL, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    gnn_train_ctx_free(l);          // one backward per forward: the weight-gradient accumulators are spent
     return GNN_OK;
+}
+
+extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
+                                       float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host,
+                                       float *d_arcs_host)
+{
+    const int rc = train_backward(l, nullptr, d_out_nodes, d_state_extra, grads_state, grads_output, bn_batch_state, bn_batch_output, d_nodes_host, d_arcs_host);
+    if (!rc) gnn_train_ctx_free(l);          // one backward per forward: the weight-gradient accumulators are spent
+    return rc;
 }
 
 extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
@@ -885,25 +1191,52 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
     ARGCHK(!(l->edge_mode && n_graphs > 0), "an edge-based loop has no graph readout");
     ARGCHK(n_targets == (n_graphs > 0 ? n_graphs : M), "%lld target rows but %lld outputs", (long long)n_targets, (long long)(n_graphs > 0 ? n_graphs : M));
     ARGCHK(n_graphs <= 0 || (ng_indptr && ng_node && ng_w), "NodeGraph^T CSR required for a graph-based step");
-    std::vector<float> h_out((size_t)M * T), h_dnodes((size_t)M * T, 0.0f), d_o;
-    int rc = gnn_loop_train_forward(l, src_indptr, src_dst, src_w, dropout_state, dropout_output, masks_state, masks_output, seed,
-                                    bn_state, bn_output, k_out, h_out.data());
+    int rc = train_forward(l, src_indptr, src_dst, src_w, dropout_state, dropout_output, masks_state, masks_output, seed, bn_state, bn_output, k_out,
+                           nullptr, false);
     if (rc) return rc;
+    // loss and d loss / d out_nodes on the device, enqueued behind the forward pass: the step waits for the device once more, at its end
+    TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
+    TrainArena *arena = static_cast<TrainArena *>(l->train_arena);
+    Buf &buf = cx->buf;
+    hipStream_t st = l->stream;
+    float *d_t = nullptr, *d_w = nullptr, *d_o = nullptr, *d_dnodes = nullptr;
+    double *d_lp = nullptr;
+    const int64_t nt = n_targets;
+    const unsigned lblocks = nt ? cdiv(nt, 256) : 0;
     double loss = 0.0;
-    if (n_graphs > 0) {                            // GNNgraphBased: out = NodeGraph^T . out_nodes (GNN.py:331-332)
-        std::vector<float> og((size_t)n_graphs * T, 0.0f);
-        for (int gi = 0; gi < n_graphs; ++gi)
-            for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e)
-                for (int t = 0; t < T; ++t) og[(size_t)gi * T + t] += ng_w[e] * h_out[(size_t)ng_node[e] * T + t];
-        loss_host(loss_kind, n_graphs, T, targets, og.data(), sample_weights, &loss, d_o);
-        for (int gi = 0; gi < n_graphs; ++gi)
-            for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e)
-                for (int t = 0; t < T; ++t) h_dnodes[(size_t)ng_node[e] * T + t] += ng_w[e] * d_o[(size_t)gi * T + t];
-    } else {
-        loss_host(loss_kind, M, T, targets, h_out.data(), sample_weights, &loss, h_dnodes);
+    if (nt) {
+        if ((rc = buf.get(&d_t, (size_t)nt * T)) || (rc = buf.get(&d_w, (size_t)nt)) || (rc = buf.get(&d_o, (size_t)nt * T)) || (rc = buf.get(&d_lp, (size_t)lblocks))) return rc;
+        HIPCHK(hipMemcpyAsync(d_t, targets, sizeof(float) * (size_t)nt * T, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_w, sample_weights, sizeof(float) * (size_t)nt, hipMemcpyHostToDevice, st));
     }
-    rc = gnn_loop_train_backward(l, h_dnodes.data(), nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr, nullptr);
+    double *h_lp = static_cast<double *>(arena->host(std::max<size_t>(sizeof(double) * lblocks, 4096)));
+    if (!h_lp) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
+    if (n_graphs > 0) {                            // GNNgraphBased: out = NodeGraph^T . out_nodes (GNN.py:331-332)
+        int32_t *d_ip = nullptr, *d_nd = nullptr;
+        float *d_nw = nullptr, *og = nullptr;
+        const int64_t ne = ng_indptr[n_graphs];
+        if ((rc = buf.get(&d_ip, (size_t)n_graphs + 1)) || (rc = buf.get(&d_nd, (size_t)ne)) || (rc = buf.get(&d_nw, (size_t)ne)) ||
+            (rc = buf.get(&og, (size_t)n_graphs * T)) || (rc = buf.get(&d_dnodes, (size_t)M * T))) return rc;
+        HIPCHK(hipMemcpyAsync(d_ip, ng_indptr, sizeof(int32_t) * ((size_t)n_graphs + 1), hipMemcpyHostToDevice, st));
+        if (ne) {
+            HIPCHK(hipMemcpyAsync(d_nd, ng_node, sizeof(int32_t) * (size_t)ne, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(d_nw, ng_w, sizeof(float) * (size_t)ne, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipMemsetAsync(d_dnodes, 0, sizeof(float) * std::max<size_t>(1, (size_t)M * T), st));
+        hipLaunchKernelGGL(k_graph_out, cdiv((int64_t)n_graphs * T, 256), 256, 0, st, n_graphs, T, d_ip, d_nd, d_nw, cx->out_nodes, og);
+        hipLaunchKernelGGL(k_loss_rows, lblocks, 256, 0, st, loss_kind, nt, T, d_t, og, d_w, d_o, d_lp);
+        hipLaunchKernelGGL(k_graph_out_bwd, cdiv((int64_t)n_graphs * T, 256), 256, 0, st, n_graphs, T, d_ip, d_nd, d_nw, d_o, d_dnodes);
+        HIPCHK(hipGetLastError());
+    } else if (nt) {
+        hipLaunchKernelGGL(k_loss_rows, lblocks, 256, 0, st, loss_kind, nt, T, d_t, cx->out_nodes, d_w, d_o, d_lp);
+        HIPCHK(hipGetLastError());
+        d_dnodes = d_o;
+    }
+    if (lblocks) HIPCHK(hipMemcpyAsync(h_lp, d_lp, sizeof(double) * lblocks, hipMemcpyDeviceToHost, st));
+    rc = train_backward(l, d_dnodes, nullptr, nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr, nullptr);
     if (rc) return rc;
+    for (unsigned b = 0; b < lblocks; ++b) loss += h_lp[b];
+    gnn_train_ctx_free(l);
     *loss_out = (float)loss;
     return GNN_OK;
 }
