@@ -180,14 +180,28 @@ class GNNnodeBased(BaseClass):
         targets = self.get_filtered_tensor(g, g.targets)
         weights = self.get_filtered_tensor(g, g.sample_weights)
         self._train_calls = getattr(self, '_train_calls', 0) + 1
-        res = loop.train_step(self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device), None, targets, weights,
+        from GNN import regularizers
+        dev_s, dev_o = self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device)
+        # Device-side optimizer step (weights, slots and gradients stay in HBM) when nothing of the step lives on the host:
+        # an optimizer that knows the engine's update rules and no kernel / bias regularizers (their gradients are host-side).
+        on_device = (getattr(self, 'device_optimizer', True) and not regularizers.any_regularizer(self.get_dense_layers())
+                     and hasattr(self.optimizer, 'device_step_args'))
+        step_args = self.optimizer.device_step_args() if on_device else None
+        if step_args is not None:
+            bn_s, bn_o = self.net_state.layers[-1], self.net_output.layers[-1]
+            loop.arm_optimizer(step_args[0], step_args[1], mean, getattr(bn_s, 'momentum', 0.99), getattr(bn_o, 'momentum', 0.99))
+        res = loop.train_step(dev_s, dev_o, None, targets, weights,
                               kind, g.nodegraph_csr() if self._graph_based else None, dropout_state=self.net_state.dropout_rates(),
                               dropout_output=self.net_output.dropout_rates(), masks_state=masks_state, masks_output=masks_output,
-                              seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),
-                              bn_output=self.net_output.bn_gamma_beta())
+                              seed=self.seed * 1000003 + self._train_calls,
+                              bn_state=None if step_args is not None else self.net_state.bn_gamma_beta(),
+                              bn_output=None if step_args is not None else self.net_output.bn_gamma_beta())
+        if step_args is not None:
+            self.net_state.mark_device_newer()
+            self.net_output.mark_device_newer()
+            return res
         k = res['k']
         # regularizer terms are part of the taped loss (reference GNN_BaseClass.py:223-235): their gradients join the device ones
-        from GNN import regularizers
         for net, key in ((self.net_state, 'grads_state'), (self.net_output, 'grads_output')):
             pen, rg = regularizers.penalty_and_gradients(net.dense_layers)
             res['loss'] += pen

@@ -64,7 +64,30 @@ def _initialize(spec, shape):
     return _INITIALIZERS[spec](shape, _rng).astype(np.float32)
 
 
+def _device_backed(name):
+    """Array attribute of a layer whose newest value may live on the device (after a device-side optimizer step, reference
+    GNN_BaseClass.py:243-247): reading it first pulls the owner Sequential's arrays back if they are stale."""
+    priv = '_' + name
+
+    def get(self):
+        owner = getattr(self, '_owner', None)
+        if owner is not None and owner._host_stale:
+            owner._pull_from_device()
+        return getattr(self, priv)
+
+    def put(self, value):
+        owner = getattr(self, '_owner', None)
+        if owner is not None and owner._host_stale:
+            owner._pull_from_device()
+        setattr(self, priv, value)
+
+    return property(get, put)
+
+
 class Dense:
+    kernel = _device_backed('kernel')
+    bias = _device_backed('bias')
+
     def __init__(self, units, activation=None, kernel_initializer='glorot_uniform', bias_initializer='zeros',
                  kernel_regularizer=None, bias_regularizer=None, input_shape=None):
         self.units, self.activation = int(units), (activation if activation is not None else 'linear')
@@ -88,6 +111,11 @@ class AlphaDropout(Dropout):
 
 
 class BatchNormalization:
+    gamma = _device_backed('gamma')
+    beta = _device_backed('beta')
+    moving_mean = _device_backed('moving_mean')
+    moving_variance = _device_backed('moving_variance')
+
     def __init__(self, epsilon=1e-3, momentum=0.99):
         self.epsilon, self.momentum = epsilon, momentum
         self.gamma = self.beta = self.moving_mean = self.moving_variance = None
@@ -118,6 +146,24 @@ class Sequential:
         if len(bns) > 1 or (bns and self.layers[-1] is not bns[0]):
             raise NotImplementedError('only one trailing BatchNormalization is supported (what GNN.MLP builds)')
         self._device = None
+        self._host_stale = False          # True: the device holds newer arrays than the layers' host copies
+        for layer in self.layers:
+            if isinstance(layer, (Dense, BatchNormalization)):
+                layer._owner = self
+
+    def mark_device_newer(self):
+        """A device-side optimizer step has updated the gnn_mlp's arrays; the host copies are refreshed on their next read."""
+        self._host_stale = True
+
+    def _pull_from_device(self):
+        self._host_stale = False
+        w = self._device.get_weights()
+        dense = self.dense_layers
+        for i, l in enumerate(dense):
+            l._kernel, l._bias = w[2 * i], w[2 * i + 1]
+        if self.batch_normalization:
+            bn = self.layers[-1]
+            bn._gamma, bn._beta, bn._moving_mean, bn._moving_variance = w[2 * len(dense):]
 
     # Keras-compatible views
     @property

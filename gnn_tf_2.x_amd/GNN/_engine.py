@@ -16,9 +16,9 @@ ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 's
 
 EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create', 'gnn_graph_create_from_arcs',
            'gnn_graph_derive', 'gnn_graph_derive_edge', 'gnn_graph_set_arc_order', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
-           'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
+           'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
-           'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loss_grad',
+           'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loss_grad',
            'gnn_loop_set_impl', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
            'gnn_comm_create_loopback', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
@@ -301,6 +301,22 @@ class Mlp:
         bp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in b])
         _check(lib().gnn_mlp_set_weights(self._h, wp, bp, _fp(bn)))
 
+    def get_weights(self):
+        """gnn_mlp_get_weights: the Keras get_weights() list as it is on the device now."""
+        w = [np.empty((int(self.dims[l]), int(self.dims[l + 1])), np.float32) for l in range(self.n)]
+        b = [np.empty((int(self.dims[l + 1]),), np.float32) for l in range(self.n)]
+        f = int(self.dims[-1])
+        bn = np.empty(4 * f, np.float32) if self.batch_normalization else None
+        wp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in w])
+        bp = (C.POINTER(C.c_float) * self.n)(*[_fp(x) for x in b])
+        _check(lib().gnn_mlp_get_weights(self._h, wp, bp, _fp(bn)))
+        out = []
+        for l in range(self.n):
+            out += [w[l], b[l]]
+        if bn is not None:
+            out += [bn[i * f:(i + 1) * f].copy() for i in range(4)]
+        return out
+
     def forward(self, x):
         x = _f32(x)
         if x.ndim != 2 or x.shape[1] != self.dims[0]:
@@ -444,6 +460,18 @@ class Loop:
         kk = int(k.value)
         return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
                     bn_batch_state=bns[:kk], bn_batch_output=bno)
+
+    def arm_optimizer(self, kind: int, hyper, mean: bool, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
+        """gnn_loop_arm_optimizer: the next train_step() also applies the optimizer update on the device."""
+        h = _f32(np.asarray(list(hyper) + [0.0] * (4 - len(hyper)), np.float32))
+        _check(lib().gnn_loop_arm_optimizer(self._h, C.c_int(kind), _fp(h), C.c_int(1 if mean else 0), C.c_float(bn_momentum_state),
+                                            C.c_float(bn_momentum_output)))
+
+    def optimizer_step(self, kind: int, hyper, state_grad_scale: float = 1.0, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
+        """gnn_loop_optimizer_step: apply the gradients of the last backward pass on the device."""
+        h = _f32(np.asarray(list(hyper) + [0.0] * (4 - len(hyper)), np.float32))
+        _check(lib().gnn_loop_optimizer_step(self._h, C.c_int(kind), _fp(h), C.c_float(state_grad_scale), C.c_float(bn_momentum_state),
+                                             C.c_float(bn_momentum_output)))
 
     @staticmethod
     def _grad_shapes(net: 'Mlp'):

@@ -7,6 +7,10 @@ class Optimizer:
     def get_config(self):
         return dict(self._config)
 
+    def device_step_args(self):
+        """(kind, hyper[<= 4]) of include/gnn_hip.h:gnn_loop_arm_optimizer for the NEXT step, counting it; None: host only."""
+        return None
+
     def apply_gradients(self, grads_and_vars):
         """[(grad, array)] -> list of updated arrays, in order (arrays are identified by position across calls)."""
         raise NotImplementedError
@@ -19,6 +23,12 @@ class Adam(Optimizer):
         self._config = dict(learning_rate=learning_rate, beta_1=beta_1, beta_2=beta_2, epsilon=epsilon)
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         self.iterations, self._m, self._v = 0, None, None
+
+    def device_step_args(self):
+        self.iterations += 1
+        t = self.iterations
+        lr_t = self.learning_rate * np.sqrt(1 - self.beta_2 ** t) / (1 - self.beta_1 ** t)
+        return 1, [lr_t, self.beta_1, self.beta_2, self.epsilon]
 
     def apply_gradients(self, grads_and_vars):
         grads_and_vars = list(grads_and_vars)
@@ -41,6 +51,9 @@ class SGD(Optimizer):
     def __init__(self, learning_rate=0.01, momentum=0.0):
         self._config = dict(learning_rate=learning_rate, momentum=momentum)
         self.learning_rate, self.momentum, self._vel = learning_rate, momentum, None
+
+    def device_step_args(self):
+        return 0, [self.learning_rate, self.momentum]
 
     def apply_gradients(self, grads_and_vars):
         grads_and_vars = list(grads_and_vars)

@@ -59,3 +59,7 @@ def penalty_and_gradients(dense_layers) -> tuple[float, list]:
             else: gb = reg.gradient(w)
         grads.append((gk, gb))
     return total, grads
+
+
+def any_regularizer(dense_layers) -> bool:
+    return any(l.kernel_regularizer is not None or l.bias_regularizer is not None for l in dense_layers)

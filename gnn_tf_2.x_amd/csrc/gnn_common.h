@@ -132,8 +132,14 @@ struct gnn_mlp {
     int device = 0;
     int n_layers = 0;
     std::vector<int> dims, acts;
-    std::vector<float *> W, b;          // device, Keras layout
-    float *bn_scale = nullptr, *bn_shift = nullptr;   // device, [dims.back()]
+    std::vector<float *> W, b;          // device, Keras layout; slices of `slab` (256-byte aligned)
+    float *slab = nullptr;              // all kernels and biases, in the order W1, b1, W2, b2, ...
+    size_t slab_floats = 0;
+    float *bn_scale = nullptr, *bn_shift = nullptr;   // device, [dims.back()]: the inference form of BatchNormalization
+    float *bn_raw = nullptr;            // device, [4 * dims.back()]: gamma | beta | moving mean | moving variance
+    // slots of the device-side optimizer (gnn_loop_optimizer_step), laid out like the gradient vector
+    // (dW1, db1, ..., dgamma, dbeta); allocated on first use, zero at that point
+    float *opt_a = nullptr, *opt_b = nullptr;
     bool has_bn = false;
     float eps = 1e-3f;
     // fused-kernel weight image (see gnn_fused.hip), rebuilt by set_weights
@@ -220,6 +226,7 @@ int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state,
 
 int gnn_launch_copy_cols(hipStream_t st, int64_t n_rows, int w, const float *src, int64_t lds_, float *dst, int64_t ldd, const int *gate, int world);
 
+int gnn_mlp_refresh_bn(gnn_mlp *m, hipStream_t st);
 // gnn_train.hip
 void gnn_train_ctx_free(gnn_loop *l);
 void gnn_train_arena_free(gnn_loop *l);

@@ -830,25 +830,45 @@ extern "C" int gnn_graph_destroy(gnn_graph *g)
 // ---------------------------------------------------------------------------------------------------------------------
 // MLP
 // ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_bn_inference_form(int f, float eps, const float *raw, float *scale, float *shift)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= f) return;
+    // same expression order as oracle/gnn_oracle.c:orc_batchnorm
+    const float g = raw[j], be = raw[f + j], mu = raw[2 * f + j], var = raw[3 * f + j];
+    const float sc = __fdiv_rn(1.0f, __fsqrt_rn(var + eps)) * g;
+    const float t = mu * sc;
+    scale[j] = sc;
+    shift[j] = be - t;
+}
+
+// scale / shift of the inference form from the raw BatchNormalization arrays on the device (after an upload or an optimizer step)
+int gnn_mlp_refresh_bn(gnn_mlp *m, hipStream_t st)
+{
+    if (!m->has_bn) return GNN_OK;
+    const int f = m->dims.back();
+    hipLaunchKernelGGL(k_bn_inference_form, cdiv(f, 64), 64, 0, st, f, m->eps, m->bn_raw, m->bn_scale, m->bn_shift);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
 static int mlp_upload(gnn_mlp *m, const float *const *W, const float *const *b, const float *bn)
 {
+    // one staging copy of the whole slab: a single transfer instead of two per layer
+    std::vector<float> stage(m->slab_floats, 0.0f);
     for (int l = 0; l < m->n_layers; ++l) {
         ARGCHK(W[l] && b[l], "W[%d]/b[%d] is NULL", l, l);
-        HIPCHK(hipMemcpy(m->W[l], W[l], sizeof(float) * (size_t)m->dims[l] * m->dims[l + 1], hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(m->b[l], b[l], sizeof(float) * (size_t)m->dims[l + 1], hipMemcpyHostToDevice));
+        memcpy(stage.data() + (m->W[l] - m->slab), W[l], sizeof(float) * (size_t)m->dims[l] * m->dims[l + 1]);
+        memcpy(stage.data() + (m->b[l] - m->slab), b[l], sizeof(float) * (size_t)m->dims[l + 1]);
     }
+    HIPCHK(hipMemcpy(m->slab, stage.data(), sizeof(float) * m->slab_floats, hipMemcpyHostToDevice));
     if (m->has_bn) {
         ARGCHK(bn, "this MLP ends with BatchNormalization: bn is required");
         const int f = m->dims.back();
-        std::vector<float> sc(f), sh(f);
-        for (int j = 0; j < f; ++j) {   // same expression order as oracle/gnn_oracle.c:orc_batchnorm
-            const float g = bn[j], be = bn[f + j], mu = bn[2 * f + j], var = bn[3 * f + j];
-            sc[j] = (1.0f / sqrtf(var + m->eps)) * g;
-            const float t = mu * sc[j];
-            sh[j] = be - t;
-        }
-        HIPCHK(hipMemcpy(m->bn_scale, sc.data(), sizeof(float) * f, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(m->bn_shift, sh.data(), sizeof(float) * f, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(m->bn_raw, bn, sizeof(float) * 4 * f, hipMemcpyHostToDevice));
+        int rc = gnn_mlp_refresh_bn(m, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(nullptr));
     }
     m->version++;
     m->pack_dirty = true;       // packed images of the fused kernel: rebuilt lazily (gnn_fused_supported)
@@ -874,11 +894,21 @@ extern "C" int gnn_mlp_create(int n_layers, const int32_t *dims, const int32_t *
     m->W.assign(n_layers, nullptr);
     m->b.assign(n_layers, nullptr);
     int rc = 0;
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    size_t off = 0;
+    for (int l = 0; l < n_layers; ++l) off += pad((size_t)dims[l] * dims[l + 1]) + pad((size_t)dims[l + 1]);
+    m->slab_floats = off;
+    rc = dev_alloc(&m->slab, off);
+    off = 0;
     for (int l = 0; l < n_layers && !rc; ++l) {
-        rc = dev_alloc(&m->W[l], (size_t)dims[l] * dims[l + 1]);
-        if (!rc) rc = dev_alloc(&m->b[l], (size_t)dims[l + 1]);
+        m->W[l] = m->slab + off; off += pad((size_t)dims[l] * dims[l + 1]);
+        m->b[l] = m->slab + off; off += pad((size_t)dims[l + 1]);
     }
-    if (!rc && m->has_bn) { rc = dev_alloc(&m->bn_scale, (size_t)dims[n_layers]); if (!rc) rc = dev_alloc(&m->bn_shift, (size_t)dims[n_layers]); }
+    if (!rc && m->has_bn) {
+        rc = dev_alloc(&m->bn_scale, (size_t)dims[n_layers]);
+        if (!rc) rc = dev_alloc(&m->bn_shift, (size_t)dims[n_layers]);
+        if (!rc) rc = dev_alloc(&m->bn_raw, (size_t)4 * dims[n_layers]);
+    }
     if (!rc) rc = mlp_upload(m, W, b, bn);
     if (rc) { gnn_mlp_destroy(m); return rc; }
     *out = m;
@@ -890,6 +920,23 @@ extern "C" int gnn_mlp_set_weights(gnn_mlp *m, const float *const *W, const floa
     ARGCHK(m && W && b, "bad arguments");
     HIPCHK(hipSetDevice(m->device));
     return mlp_upload(m, W, b, bn);
+}
+
+extern "C" int gnn_mlp_get_weights(gnn_mlp *m, float *const *W, float *const *b, float *bn)
+{
+    ARGCHK(m && W && b, "bad arguments");
+    ARGCHK(!m->has_bn || bn, "this MLP ends with BatchNormalization: bn [4 * width] is required");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());                 // an optimizer step may still be running on a loop's stream
+    std::vector<float> stage(m->slab_floats);
+    HIPCHK(hipMemcpy(stage.data(), m->slab, sizeof(float) * m->slab_floats, hipMemcpyDeviceToHost));
+    for (int l = 0; l < m->n_layers; ++l) {
+        ARGCHK(W[l] && b[l], "W[%d]/b[%d] is NULL", l, l);
+        memcpy(W[l], stage.data() + (m->W[l] - m->slab), sizeof(float) * (size_t)m->dims[l] * m->dims[l + 1]);
+        memcpy(b[l], stage.data() + (m->b[l] - m->slab), sizeof(float) * (size_t)m->dims[l + 1]);
+    }
+    if (m->has_bn) HIPCHK(hipMemcpy(bn, m->bn_raw, sizeof(float) * 4 * m->dims.back(), hipMemcpyDeviceToHost));
+    return GNN_OK;
 }
 
 extern "C" int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y)
@@ -917,9 +964,9 @@ extern "C" int gnn_mlp_destroy(gnn_mlp *m)
 {
     if (!m) return GNN_OK;
     (void)hipSetDevice(m->device);
-    for (float *p : m->W) (void)hipFree(p);
-    for (float *p : m->b) (void)hipFree(p);
-    (void)hipFree(m->bn_scale); (void)hipFree(m->bn_shift);
+    (void)hipFree(m->slab);
+    (void)hipFree(m->bn_scale); (void)hipFree(m->bn_shift); (void)hipFree(m->bn_raw);
+    (void)hipFree(m->opt_a); (void)hipFree(m->opt_b);
     gnn_fused_release(m);
     delete m;
     return GNN_OK;

@@ -449,6 +449,9 @@ struct TrainArena {
         off = bytes;
         return s.p;
     }
+    // optimizer armed for the next gnn_loop_train_step (gnn_loop_arm_optimizer): applied behind the backward pass, before the
+    // step's only wait for the device
+    struct { bool armed = false; int kind = 0; float h[4] = {0, 0, 0, 0}; bool mean = false; float mom_s = 0.99f, mom_o = 0.99f; } opt;
     // pinned host words for the results the host waits for (iteration gates, loss partials)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -505,13 +508,16 @@ struct Net {
     size_t g_total = 0;
     float *part = nullptr;        // [chunks of the rows][g_total]: the partial gradients of ONE net_backward call
     int64_t part_rows = -1;
+    float *stats_all = nullptr;   // [max forward calls][2 F]: batch mean | biased batch variance of every BatchNormalization call, in call order
+    int calls = 0, max_calls = 0;
 };
 
 inline unsigned elementwise_grid(int64_t total) { return (unsigned)std::min<int64_t>(std::max<int64_t>(1, (total + 255) / 256), 2048); }
 
-int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host)
+int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host, int max_calls)
 {
     net.m = m;
+    net.max_calls = max_calls;
     const int L = m->n_layers;
     net.rate.assign(rates, rates + L + 1);
     net.WT.assign(L, nullptr);
@@ -530,7 +536,11 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
         int rc = buf.get(&net.gamma, (size_t)2 * F);
         if (rc) return rc;
         net.beta = net.gamma + F;
-        HIPCHK(hipMemcpyAsync(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice, st));
+        // gamma | beta: the caller's arrays, or (NULL) the MLP's own device copy (the one the device-side optimizer updates)
+        if (bn_gamma_beta_host) HIPCHK(hipMemcpyAsync(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice, st));
+        else { net.gamma = m->bn_raw; net.beta = m->bn_raw + F; }
+        if ((rc = buf.get(&net.stats_all, (size_t)std::max(1, max_calls) * 2 * F))) return rc;
+        HIPCHK(hipMemsetAsync(net.stats_all, 0, sizeof(float) * (size_t)std::max(1, max_calls) * 2 * F, st));
         net.g_off.push_back(off); off += F;
         net.g_off.push_back(off); off += F;
     }
@@ -543,7 +553,7 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
 
 // training-mode forward of one Sequential on n rows (x: [n, dims[0]]); *y_out: [n, dims.back()].  keep0 != NULL: the Dropout
 // in front of the first Dense layer has been applied by the producer of x (k_train_input), its mask is keep0.
-int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, uint8_t *keep0, const uint8_t *masks, uint64_t seed, NetCache &c,
+int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t *keep0, const uint8_t *masks, uint64_t seed, NetCache &c,
                 float **y_out)
 {
     const gnn_mlp *m = net.m;
@@ -584,8 +594,9 @@ int net_forward(hipStream_t st, Buf &buf, const Net &net, int64_t n, float *x, u
     if (m->has_bn) {
         const int F = m->dims.back();
         float *y = nullptr;
-        if ((rc = buf.get(&c.xhat, (size_t)n * F)) || (rc = buf.get(&c.stats, (size_t)2 * F)) || (rc = buf.get(&y, (size_t)n * F))) return rc;
-        HIPCHK(hipMemsetAsync(c.stats, 0, sizeof(float) * 2 * F, st));
+        if ((rc = buf.get(&c.xhat, (size_t)n * F)) || (rc = buf.get(&y, (size_t)n * F))) return rc;
+        if (net.calls >= std::max(1, net.max_calls)) return gnn_fail(GNN_ERR_STATE, "more BatchNormalization calls than announced");
+        c.stats = net.stats_all + (size_t)net.calls++ * 2 * F;
         if (n > 0) {
             const int64_t rpb = rows_per_block(n);
             const int parts = (int)cdiv(n, rpb);
@@ -870,6 +881,8 @@ struct TrainCtx {
     float *state = nullptr, *out_nodes = nullptr;
     int k = 0;
     int64_t N = 0, M = 0;
+    bool backward_done = false;   // the gradients are complete (and the activations spent)
+    bool applied = false;         // gnn_loop_optimizer_step has consumed them
 };
 
 constexpr int TRAIN_CHUNK = 5;     // bodies enqueued between two looks at the iteration gates (see train_forward)
@@ -912,8 +925,6 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     ARGCHK(l && dropout_state && dropout_output && k_out, "bad arguments");
     ARGCHK(l->world == 1, "training is single-GPU");
     ARGCHK(l->edge_mode == l->edge_expected, "edge-based net_output: call gnn_loop_set_edge_readout first");
-    ARGCHK(!l->st->has_bn || bn_state, "net_state ends with BatchNormalization: gamma|beta required");
-    ARGCHK(!l->ou->has_bn || bn_output, "net_output ends with BatchNormalization: gamma|beta required");
     if (!l->have_state0 && l->D) return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
     gnn_graph *g = l->g;
     const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked, E = g->E;
@@ -931,7 +942,7 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     Buf &buf = cx->buf;
     Net &ns = cx->ns, &no_ = cx->no_;
     int rc;
-    if ((rc = net_setup(st, buf, ns, l->st, dropout_state, bn_state)) || (rc = net_setup(st, buf, no_, l->ou, dropout_output, bn_output))) return rc;
+    if ((rc = net_setup(st, buf, ns, l->st, dropout_state, bn_state, l->max_iter)) || (rc = net_setup(st, buf, no_, l->ou, dropout_output, bn_output, 1))) return rc;
     // Adjacency by source for the transposed aggregation of the backward pass: the caller's arrays, or (NULL) the graph's
     // own copy, built once from its CSR by destination (a stable counting sort by source keeps destinations ascending)
     if (src_indptr) {
@@ -1071,11 +1082,11 @@ extern "C" int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, co
 
 // d_out_dev: d loss / d out_nodes already on the device (gnn_loop_train_step), else d_out_host is uploaded
 static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host, const float *d_state_extra, float *grads_state,
-                          float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host, float *d_arcs_host)
+                          float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host, float *d_arcs_host, bool sync)
 {
     ARGCHK(l && grads_state && grads_output, "bad arguments");
     TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
-    if (!cx) return gnn_fail(GNN_ERR_STATE, "gnn_loop_train_forward has not been called");
+    if (!cx || cx->backward_done) return gnn_fail(GNN_ERR_STATE, "gnn_loop_train_forward has not been called (one backward per forward)");
     gnn_graph *g = l->g;
     const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked;
     const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->ou->dims[0], NL = g->NL, k = cx->k;
@@ -1163,7 +1174,8 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
     }
     if (want_nodes && N)        // D == 0: state_0 = nodes (GNN.py:265), so the gradient of the initial state IS the label gradient
         HIPCHK(hipMemcpyAsync(d_nodes_host, l->D ? d_nodes : d_state, sizeof(float) * (size_t)N * NL, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (sync) HIPCHK(hipStreamSynchronize(st));
+    cx->backward_done = true;
     return GNN_OK;
 }
 
@@ -1171,9 +1183,119 @@ extern "C" int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, co
                                        float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host,
                                        float *d_arcs_host)
 {
-    const int rc = train_backward(l, nullptr, d_out_nodes, d_state_extra, grads_state, grads_output, bn_batch_state, bn_batch_output, d_nodes_host, d_arcs_host);
-    if (!rc) gnn_train_ctx_free(l);          // one backward per forward: the weight-gradient accumulators are spent
+    // the context stays (its gradients feed gnn_loop_optimizer_step) until the next forward; a second backward is refused
+    return train_backward(l, nullptr, d_out_nodes, d_state_extra, grads_state, grads_output, bn_batch_state, bn_batch_output, d_nodes_host, d_arcs_host, true);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Optimizer step on the device (reference GNN_BaseClass.py:243-247: optimizer.apply_gradients on the trainable variables of
+// both nets; Keras BatchNormalization moving statistics): the weights, the optimizer slots and the gradients never leave HBM.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct ParamMap {                 // gradient vector index -> parameter array
+    int n = 0;
+    int goff[36];                 // [n + 1]
+    float *p[35];
+};
+
+// kind 0, SGD: h = {learning rate, momentum}: v <- momentum v - lr g, p <- p + v
+// kind 1, Adam (Keras): h = {lr_t = lr sqrt(1 - b2^t) / (1 - b1^t), b1, b2, epsilon}: m, v updated, p <- p - lr_t m / (sqrt(v) + epsilon)
+__global__ void k_optimizer(ParamMap mp, const float *g, float gscale, float *sa, float *sb, int kind, float h0, float h1, float h2, float h3)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= mp.goff[mp.n]) return;
+    int a = 0;
+    while (j >= mp.goff[a + 1]) ++a;
+    float *p = mp.p[a] + (j - mp.goff[a]);
+    const float gr = g[j] * gscale;
+    if (kind == 1) {
+        const float m = h1 * sa[j] + (1.0f - h1) * gr;
+        const float v = h2 * sb[j] + (1.0f - h2) * gr * gr;
+        sa[j] = m; sb[j] = v;
+        *p = *p - h0 * m / (sqrtf(v) + h3);
+    } else {
+        const float v = h1 * sa[j] - h0 * gr;
+        sa[j] = v;
+        *p = *p + v;
+    }
+}
+
+// moving <- moving * momentum + batch * (1 - momentum), once per BatchNormalization call, in call order
+__global__ void k_bn_moving(int F, int calls, const float *stats_all, float momentum, float *raw)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F) return;
+    float mean = raw[2 * F + j], var = raw[3 * F + j];
+    for (int c = 0; c < calls; ++c) {
+        mean = mean * momentum + stats_all[(size_t)c * 2 * F + j] * (1.0f - momentum);
+        var = var * momentum + stats_all[(size_t)c * 2 * F + F + j] * (1.0f - momentum);
+    }
+    raw[2 * F + j] = mean; raw[3 * F + j] = var;
+}
+
+int optimizer_apply(hipStream_t st, gnn_mlp *m, const Net &net, int calls, int kind, const float *h, float gscale, float bn_momentum)
+{
+    const size_t total = net.g_total;
+    if (!m->opt_a) {
+        if (hipMalloc((void **)&m->opt_a, sizeof(float) * total) != hipSuccess || hipMalloc((void **)&m->opt_b, sizeof(float) * total) != hipSuccess)
+            return gnn_fail(GNN_ERR_HIP, "hipMalloc of the optimizer slots failed");
+        HIPCHK(hipMemsetAsync(m->opt_a, 0, sizeof(float) * total, st));
+        HIPCHK(hipMemsetAsync(m->opt_b, 0, sizeof(float) * total, st));
+    }
+    ParamMap mp;
+    const int L = m->n_layers;
+    for (int l = 0; l < L; ++l) {
+        mp.goff[2 * l] = (int)net.g_off[2 * l]; mp.p[2 * l] = m->W[l];
+        mp.goff[2 * l + 1] = (int)net.g_off[2 * l + 1]; mp.p[2 * l + 1] = m->b[l];
+    }
+    mp.n = 2 * L;
+    if (m->has_bn) {
+        const int F = m->dims.back();
+        mp.goff[mp.n] = (int)net.g_off[2 * L]; mp.p[mp.n] = m->bn_raw; ++mp.n;
+        mp.goff[mp.n] = (int)net.g_off[2 * L + 1]; mp.p[mp.n] = m->bn_raw + F; ++mp.n;
+    }
+    mp.goff[mp.n] = (int)total;
+    hipLaunchKernelGGL(k_optimizer, cdiv((int64_t)total, 256), 256, 0, st, mp, net.grads, gscale, m->opt_a, m->opt_b, kind, h[0], h[1], h[2], h[3]);
+    HIPCHK(hipGetLastError());
+    if (m->has_bn) {
+        const int F = m->dims.back();
+        if (calls > 0) hipLaunchKernelGGL(k_bn_moving, cdiv(F, 64), 64, 0, st, F, calls, net.stats_all, bn_momentum, m->bn_raw);
+        HIPCHK(hipGetLastError());
+        int rc = gnn_mlp_refresh_bn(m, st);
+        if (rc) return rc;
+    }
+    m->version++;
+    m->pack_dirty = true;
+    return GNN_OK;
+}
+}   // namespace
+
+extern "C" int gnn_loop_optimizer_step(gnn_loop *l, int kind, const float *hyper, float state_grad_scale, float bn_momentum_state,
+                                       float bn_momentum_output)
+{
+    ARGCHK(l && hyper && (kind == 0 || kind == 1), "bad arguments (kind: 0 SGD, 1 Adam)");
+    TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
+    if (!cx || !cx->backward_done || cx->applied) return gnn_fail(GNN_ERR_STATE, "no fresh gradients: run gnn_loop_train_step (or forward + backward) first");
+    ARGCHK(l->st->n_layers <= 16 && l->ou->n_layers <= 16, "too many layers");
+    HIPCHK(hipSetDevice(l->device));
+    hipStream_t st = l->stream;
+    int rc = optimizer_apply(st, l->st, cx->ns, cx->k, kind, hyper, state_grad_scale, bn_momentum_state);
+    if (!rc) rc = optimizer_apply(st, l->ou, cx->no_, cx->M > 0 ? 1 : 0, kind, hyper, 1.0f, bn_momentum_output);
+    cx->applied = true;
+    if (!rc) HIPCHK(hipStreamSynchronize(st));   // other loops (other streams) may use these weights next
     return rc;
+}
+
+extern "C" int gnn_loop_arm_optimizer(gnn_loop *l, int kind, const float *hyper, int mean, float bn_momentum_state, float bn_momentum_output)
+{
+    ARGCHK(l && hyper && (kind == 0 || kind == 1), "bad arguments (kind: 0 SGD, 1 Adam)");
+    ARGCHK(l->st->n_layers <= 16 && l->ou->n_layers <= 16, "too many layers");
+    if (!l->train_arena) l->train_arena = new TrainArena();
+    TrainArena *arena = static_cast<TrainArena *>(l->train_arena);
+    arena->opt.armed = true; arena->opt.kind = kind; arena->opt.mean = mean != 0;
+    for (int i = 0; i < 4; ++i) arena->opt.h[i] = hyper[i];
+    arena->opt.mom_s = bn_momentum_state; arena->opt.mom_o = bn_momentum_output;
+    return GNN_OK;
 }
 
 extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
@@ -1233,10 +1355,18 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
         d_dnodes = d_o;
     }
     if (lblocks) HIPCHK(hipMemcpyAsync(h_lp, d_lp, sizeof(double) * lblocks, hipMemcpyDeviceToHost, st));
-    rc = train_backward(l, d_dnodes, nullptr, nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr, nullptr);
+    rc = train_backward(l, d_dnodes, nullptr, nullptr, grads_state, grads_output, bn_batch_state, bn_batch_output, nullptr, nullptr, false);
     if (rc) return rc;
+    if (arena->opt.armed) {                        // gnn_loop_arm_optimizer: the update rides on this step's stream work
+        arena->opt.armed = false;
+        const float gscale = (arena->opt.mean && cx->k > 0) ? 1.0f / (float)cx->k : 1.0f;
+        if ((rc = optimizer_apply(st, l->st, cx->ns, cx->k, arena->opt.kind, arena->opt.h, gscale, arena->opt.mom_s))) return rc;
+        if ((rc = optimizer_apply(st, l->ou, cx->no_, cx->M > 0 ? 1 : 0, arena->opt.kind, arena->opt.h, 1.0f, arena->opt.mom_o))) return rc;
+        cx->applied = true;
+    }
+    HIPCHK(hipStreamSynchronize(st));
     for (unsigned b = 0; b < lblocks; ++b) loss += h_lp[b];
-    gnn_train_ctx_free(l);
     *loss_out = (float)loss;
     return GNN_OK;
 }
+

@@ -105,7 +105,10 @@ int gnn_graph_destroy(gnn_graph *g);
 int gnn_mlp_create(int n_layers, const int32_t *dims, const int32_t *acts, const float *const *W, const float *const *b,
                    const float *bn, float bn_eps, int device, gnn_mlp **out);
 int gnn_mlp_set_weights(gnn_mlp *m, const float *const *W, const float *const *b, const float *bn);   /* GNN.py:168-172 */
-int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y);   /* Sequential.__call__(x, training=False) */
+int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y);
+/* Sequential.get_weights(): W[l] [dims[l] x dims[l+1]], b[l] [dims[l+1]], bn [4 x width] = gamma | beta | moving_mean |
+ * moving_variance (NULL without BatchNormalization); waits for the device first (a device-side optimizer step may be running) */
+int gnn_mlp_get_weights(gnn_mlp *m, float *const *W, float *const *b, float *bn);   /* Sequential.__call__(x, training=False) */
 int gnn_mlp_destroy(gnn_mlp *m);
 
 /* ---- loop -------------------------------------------------------------------------------------------------------
@@ -179,6 +182,20 @@ int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t
 int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *d_state_extra, float *grads_state,
                             float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes,
                             float *d_arc_labels);
+/* Optimizer step on the device (reference GNN_BaseClass.py:243-247, optimizer.apply_gradients on the trainable variables of
+ * both nets, and the moving statistics Keras BatchNormalization updates in training mode): weights, optimizer slots (kept with
+ * the gnn_mlp) and gradients stay in HBM.  kind 0 = SGD, hyper = {learning_rate, momentum, -, -}; kind 1 = Adam, hyper =
+ * {lr_t = lr sqrt(1 - beta_2^t) / (1 - beta_1^t), beta_1, beta_2, epsilon} (the caller counts t).
+ *   gnn_loop_arm_optimizer   one-shot: the NEXT gnn_loop_train_step applies the update behind its backward pass, before the
+ *                            step's single wait for the device; mean != 0 divides the net_state gradients by the iteration
+ *                            count (GNN_BaseClass.py:241).  The gradients returned by that step are the raw ones.
+ *   gnn_loop_optimizer_step  the same as a call of its own, after gnn_loop_train_step or forward + backward (once per backward);
+ *                            state_grad_scale multiplies the net_state gradients.
+ * With bn_state / bn_output NULL in the train calls, gamma / beta are the gnn_mlp's own device copy (the one updated here).
+ * gnn_mlp_get_weights (above) reads the current arrays back. */
+int gnn_loop_arm_optimizer(gnn_loop *l, int kind, const float *hyper, int mean, float bn_momentum_state, float bn_momentum_output);
+int gnn_loop_optimizer_step(gnn_loop *l, int kind, const float *hyper, float state_grad_scale, float bn_momentum_state,
+                            float bn_momentum_output);
 int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets, const float *out,
                   const float *sample_weights, double *loss, float *d_out);
 /* selects the implementation:

@@ -509,3 +509,51 @@ def test_training_forward_stops_at_convergence():
     for got, want in zip(res['grads_output'], ref['grads_output']):
         assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want)))
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('opt_name,graph_based', [('Adam', False), ('Adam', True), ('SGD', False)])
+def test_device_optimizer_matches_host_optimizer(opt_name, graph_based):
+    """gnn_loop_arm_optimizer (weights, slots, gradients stay in HBM) against the NumPy optimizers of GNN/optimizers.py on the
+    same gradients: three steps of the same model trained both ways must leave the same weights, BatchNormalization
+    moving statistics included (reference GNN_BaseClass.py:243-247)."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNnodeBased, GNNgraphBased
+    from GNN.MLP import MLP, set_seed
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(5)
+    gg = []
+    for i in range(4):
+        n = 50
+        nodes = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+        tg = np.eye(2)[[i % 2]] if graph_based else np.eye(2)[rng.integers(0, 2, n)]
+        gg.append(GraphObject(arcs=random_arcs(rng, n, 150, 1), nodes=nodes, targets=tg, problem_based='g' if graph_based else 'n'))
+    batch = GraphObject.merge(gg, problem_based='g' if graph_based else 'n', aggregation_mode='average')
+
+    def model(device_optimizer):
+        set_seed(3)
+        st = MLP(1 + 2 * 3, [8, 3], 'selu', 'glorot_normal', 'zeros')                       # BatchNormalization on (default)
+        ou = MLP(3, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
+        opt = optimizers.Adam(0.01) if opt_name == 'Adam' else optimizers.SGD(0.05, momentum=0.9)
+        m = (GNNgraphBased if graph_based else GNNnodeBased)(net_state=st, net_output=ou, optimizer=opt, loss_function=losses.categorical_crossentropy,
+                                                             loss_arguments=None, state_vect_dim=0, max_iteration=3, threshold=0.001, addressed_problem='c')
+        m.device_optimizer = device_optimizer
+        return m
+
+    host, dev = model(False), model(True)
+    for a, b in zip(host.net_state.get_weights(), dev.net_state.get_weights()):
+        assert np.array_equal(a, b)
+    for _ in range(3):
+        rh = host.training_step(batch, True)
+        rd = dev.training_step(batch, True)
+        assert rh['k'] == rd['k'] and abs(rh['loss'] - rd['loss']) <= 1e-4 * max(1.0, abs(rh['loss']))
+    assert dev.net_state._host_stale                       # nothing has been read back yet
+    for net_h, net_d in ((host.net_state, dev.net_state), (host.net_output, dev.net_output)):
+        for a, b in zip(net_h.get_weights(), net_d.get_weights()):
+            assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, np.max(np.abs(a)))
+    assert not dev.net_state._host_stale
+    # the refreshed host copies and the device agree: an inference Loop after set_weights(get_weights()) gives the same output
+    k0, _, out0 = dev.Loop(batch)
+    dev.net_state.set_weights(dev.net_state.get_weights())
+    k1, _, out1 = dev.Loop(batch)
+    assert k0 == k1 and np.array_equal(out0, out1)
