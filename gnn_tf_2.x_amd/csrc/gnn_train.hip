@@ -137,98 +137,159 @@ __global__ void k_act_bwd(int64_t n, int F, float *d, const float *a, int act)
 }
 
 // Row chunks.  Every reduction over the rows of a matrix (BatchNormalization statistics, bias / weight / gamma / beta gradients)
-// is done per chunk of rows_per_block(n) rows; a chunk leaves a partial result and the partials are added in chunk order
+// is done per chunk of rows_per_block(n) rows; a chunk leaves a partial result and the partials are added in a fixed order
 // (k_sum_parts, or by the consumer itself): run-to-run identical sums without float atomics.
+// Thread layout of the column reductions: 256 threads = CW columns x (256 / CW) row lanes, CW = 2^cw_shift >= min(F, 32), so that
+// narrow matrices (F = 14, 16) still use the whole block; rows are read four at a time (independent loads in flight).
+inline int column_shift(int F) { int s = 0; while ((1 << s) < F && s < 5) ++s; return s; }
 
-// partial sums of d * xhat and d over the rows of chunk blockIdx.y: out0 / out1 [chunk * ostride + j]; 256 threads = 32 columns x 8 row lanes
-__global__ void k_colreduce2(int64_t n, int F, const float *x, const float *y, float *out0, float *out1, int64_t ostride, int64_t rows_per_block)
+// partial sums of x * y and x over the rows of chunk blockIdx.y: out0 / out1 [chunk * ostride + j]
+__global__ void __launch_bounds__(256) k_colreduce2(int64_t n, int F, int cw_shift, const float *__restrict__ x, const float *__restrict__ y, float *out0,
+                                                    float *out1, int64_t ostride, int64_t rows_per_block)
 {
-    __shared__ float s0[8][33], s1[8][33];
-    const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + c;
+    __shared__ float s0[256], s1[256];
+    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
+    const int c = threadIdx.x & (CW - 1), ry = threadIdx.x >> cw_shift;
+    const int j = blockIdx.x * CW + c;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     float a0 = 0.0f, a1 = 0.0f;
-    if (j < F)
-        for (int64_t r = r0 + ry; r < r1; r += 8) {
-            const float v = x[r * F + j];
-            a0 += v * y[r * F + j];
-            a1 += v;
+    if (j < F) {
+        int64_t r = r0 + ry;
+        for (; r + 3 * RL < r1; r += 4 * RL) {
+            float xv[4], yv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { xv[q] = x[(r + q * RL) * F + j]; yv[q] = y[(r + q * RL) * F + j]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a0 += xv[q] * yv[q]; a1 += xv[q]; }
         }
-    s0[ry][c] = a0; s1[ry][c] = a1;
+        for (; r < r1; r += RL) { const float v = x[r * F + j]; a0 += v * y[r * F + j]; a1 += v; }
+    }
+    s0[threadIdx.x] = a0; s1[threadIdx.x] = a1;
     __syncthreads();
     if (ry == 0 && j < F) {
-        for (int t = 1; t < 8; ++t) { a0 += s0[t][c]; a1 += s1[t][c]; }
+        for (int t = 1; t < RL; ++t) { a0 += s0[t * CW + c]; a1 += s1[t * CW + c]; }
         out0[(size_t)blockIdx.y * ostride + j] = a0;
         out1[(size_t)blockIdx.y * ostride + j] = a1;
     }
 }
 
-// out[t] += part[0][t] + part[1][t] + ... (ascending chunk index), t < count
-__global__ void k_sum_parts(int parts, int64_t count, const float *part, float *out)
+// out[t] += part[0][t] + part[1][t] + ... for the 64 columns of block `bid`: four lanes per column take every fourth chunk, their
+// sums are added in lane order
+__device__ __forceinline__ void sum_parts_block(int bid, int parts, int64_t count, const float *__restrict__ part, float *out, float *sp /* [256] */)
 {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
+    const int c = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const int64_t t = (int64_t)bid * 64 + c;
     float acc = 0.0f;
-    for (int z = 0; z < parts; ++z) acc += part[(size_t)z * count + t];
-    out[t] += acc;
+    if (t < count) {
+#pragma unroll 8
+        for (int z = zl; z < parts; z += 4) acc += part[(size_t)z * count + t];
+    }
+    sp[threadIdx.x] = acc;
+    __syncthreads();
+    if (zl == 0 && t < count) out[t] += ((acc + sp[64 + c]) + sp[128 + c]) + sp[192 + c];
+}
+
+__global__ void __launch_bounds__(256) k_sum_parts(int parts, int64_t count, const float *part, float *out)
+{
+    __shared__ float sp[256];
+    sum_parts_block(blockIdx.x, parts, count, part, out, sp);
 }
 
 // BatchNormalization, training mode, forward statistics of one row chunk: part[chunk][j] = chunk mean, part[chunk][F + j] =
 // sum over the chunk of (x - chunk mean)^2 (two passes over the chunk's rows)
-__global__ void k_bn_stats(int64_t n, int F, const float *h, float *part, int64_t rows_per_block)
+__global__ void __launch_bounds__(256) k_bn_stats(int64_t n, int F, int cw_shift, const float *__restrict__ h, float *part, int64_t rows_per_block)
 {
-    __shared__ float s0[8][33];
+    __shared__ float s0[256];
     __shared__ float mu[32];
-    const int c = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + c;
+    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
+    const int c = threadIdx.x & (CW - 1), ry = threadIdx.x >> cw_shift;
+    const int j = blockIdx.x * CW + c;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     float a0 = 0.0f;
-    if (j < F) for (int64_t r = r0 + ry; r < r1; r += 8) a0 += h[r * F + j];
-    s0[ry][c] = a0;
+    if (j < F) {
+        int64_t r = r0 + ry;
+        for (; r + 3 * RL < r1; r += 4 * RL) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = h[(r + q * RL) * F + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a0 += v[q];
+        }
+        for (; r < r1; r += RL) a0 += h[r * F + j];
+    }
+    s0[threadIdx.x] = a0;
     __syncthreads();
     if (ry == 0) {
-        for (int t = 1; t < 8; ++t) a0 += s0[t][c];
+        for (int t = 1; t < RL; ++t) a0 += s0[t * CW + c];
         mu[c] = a0 / (float)(r1 - r0);
     }
     __syncthreads();
     const float m = mu[c];
     a0 = 0.0f;
-    if (j < F) for (int64_t r = r0 + ry; r < r1; r += 8) { const float dv = h[r * F + j] - m; a0 += dv * dv; }
+    if (j < F) {
+        int64_t r = r0 + ry;
+        for (; r + 3 * RL < r1; r += 4 * RL) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = h[(r + q * RL) * F + j] - m;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a0 += v[q] * v[q];
+        }
+        for (; r < r1; r += RL) { const float dv = h[r * F + j] - m; a0 += dv * dv; }
+    }
     __syncthreads();
-    s0[ry][c] = a0;
+    s0[threadIdx.x] = a0;
     __syncthreads();
     if (ry == 0 && j < F) {
-        for (int t = 1; t < 8; ++t) a0 += s0[t][c];
+        for (int t = 1; t < RL; ++t) a0 += s0[t * CW + c];
         part[(size_t)blockIdx.y * 2 * F + j] = m;
         part[(size_t)blockIdx.y * 2 * F + F + j] = a0;
     }
 }
 
-// batch mean / biased batch variance from the chunk statistics (pairwise update in chunk order), then xhat = (h - mean) / sqrt(var + eps),
-// y = gamma xhat + beta.  Every block combines the (few) chunks itself; block 0 leaves [mean | var] in stats for the
-// backward pass and the moving statistics.  Dynamic LDS: 2 F floats.
-__global__ void k_bn_apply(int64_t n, int F, const float *h, const float *part, int parts, int64_t rows_per_block, float eps,
-                           const float *gamma, const float *beta, float *xhat, float *y, float *stats)
+// (count, mean, M2) of two disjoint sets of rows -> of their union (exact in real arithmetic; the order of the calls is fixed)
+__device__ __forceinline__ void stats_merge(float &cnt, float &mean, float &m2, float cb, float mb, float qb)
+{
+    if (cb == 0.0f) return;
+    const float delta = mb - mean, tot = cnt + cb;
+    mean = mean + delta * (cb / tot);
+    m2 = m2 + qb + delta * delta * (cnt * cb / tot);
+    cnt = tot;
+}
+
+// batch mean / biased batch variance from the chunk statistics, then xhat = (h - mean) / sqrt(var + eps), y = gamma xhat + beta.
+// Every block combines the chunks itself (256 / CW lanes per column take every (256 / CW)-th chunk, the lanes are merged in order);
+// block 0 leaves [mean | var] in stats for the backward pass and the moving statistics.  Dynamic LDS: 2 F floats.
+__global__ void __launch_bounds__(256) k_bn_apply(int64_t n, int F, int cw_shift, const float *__restrict__ h, const float *__restrict__ part, int parts,
+                                                  int64_t rows_per_block, float eps, const float *gamma, const float *beta, float *xhat, float *y, float *stats)
 {
     extern __shared__ float bsh[];
+    __shared__ float sc[3][256];
     float *sm = bsh, *sinv = bsh + F;
-    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+    const int CW = 1 << cw_shift, ZL = 256 >> cw_shift;
+    const int c = threadIdx.x & (CW - 1), zl = threadIdx.x >> cw_shift;
+    for (int jb = 0; jb < F; jb += CW) {
+        const int j = jb + c;
         float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
-        for (int z = 0; z < parts; ++z) {
-            const int64_t r0 = (int64_t)z * rows_per_block;
-            const float nz = (float)((r0 + rows_per_block < n ? r0 + rows_per_block : n) - r0);
-            const float mz = part[(size_t)z * 2 * F + j], qz = part[(size_t)z * 2 * F + F + j];
-            const float delta = mz - mean, tot = cnt + nz;
-            mean = mean + delta * (nz / tot);
-            m2 = m2 + qz + delta * delta * (cnt * nz / tot);
-            cnt = tot;
+        if (j < F) {
+#pragma unroll 4
+            for (int z = zl; z < parts; z += ZL) {
+                const int64_t r0 = (int64_t)z * rows_per_block;
+                const float nz = (float)((r0 + rows_per_block < n ? r0 + rows_per_block : n) - r0);
+                stats_merge(cnt, mean, m2, nz, part[(size_t)z * 2 * F + j], part[(size_t)z * 2 * F + F + j]);
+            }
         }
-        const float var = m2 / (float)n;
-        sm[j] = mean;
-        sinv[j] = 1.0f / sqrtf(var + eps);
-        if (blockIdx.x == 0) { stats[j] = mean; stats[F + j] = var; }
+        sc[0][threadIdx.x] = cnt; sc[1][threadIdx.x] = mean; sc[2][threadIdx.x] = m2;
+        __syncthreads();
+        if (zl == 0 && j < F) {
+            for (int t = 1; t < ZL; ++t) stats_merge(cnt, mean, m2, sc[0][t * CW + c], sc[1][t * CW + c], sc[2][t * CW + c]);
+            const float var = m2 / (float)n;
+            sm[j] = mean;
+            sinv[j] = 1.0f / sqrtf(var + eps);
+            if (blockIdx.x == 0) { stats[j] = mean; stats[F + j] = var; }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const int j = (int)(i % F);
@@ -241,17 +302,30 @@ __global__ void k_bn_apply(int64_t n, int F, const float *h, const float *part, 
 // d x = inv / n * (n * dxh - sum dxh - xhat * sum(dxh * xhat)), dxh = d y * gamma, with sum d y * xhat / sum d y added up from the
 // chunk partials p_dyx / p_dy [chunk * pstride + j] (the same numbers k_sum_parts adds into the gamma / beta gradients);
 // then, fused, the derivative of the layer's activation: d <- d x * act'(a) (act < 0: none).  Dynamic LDS: 2 F floats.
-__global__ void k_bn_bwd_apply(int64_t n, int F, float *d, const float *xhat, const float *gamma, const float *stats, float eps,
-                               const float *p_dyx, const float *p_dy, int64_t pstride, int parts, const float *a, int act)
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_shift, float *d, const float *__restrict__ xhat, const float *gamma,
+                                                      const float *stats, float eps, const float *__restrict__ p_dyx, const float *__restrict__ p_dy,
+                                                      int64_t pstride, int parts, const float *__restrict__ a, int act)
 {
     extern __shared__ float bsh[];
+    __shared__ float sc[2][256];
     float *s_dyx = bsh, *s_dy = bsh + F;
-    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+    const int CW = 1 << cw_shift, ZL = 256 >> cw_shift;
+    const int c = threadIdx.x & (CW - 1), zl = threadIdx.x >> cw_shift;
+    for (int jb = 0; jb < F; jb += CW) {
+        const int j = jb + c;
         float a0 = 0.0f, a1 = 0.0f;
-        for (int z = 0; z < parts; ++z) { a0 += p_dyx[(size_t)z * pstride + j]; a1 += p_dy[(size_t)z * pstride + j]; }
-        s_dyx[j] = a0; s_dy[j] = a1;
+        if (j < F) {
+#pragma unroll 4
+            for (int z = zl; z < parts; z += ZL) { a0 += p_dyx[(size_t)z * pstride + j]; a1 += p_dy[(size_t)z * pstride + j]; }
+        }
+        sc[0][threadIdx.x] = a0; sc[1][threadIdx.x] = a1;
+        __syncthreads();
+        if (zl == 0 && j < F) {
+            for (int t = 1; t < ZL; ++t) { a0 += sc[0][t * CW + c]; a1 += sc[1][t * CW + c]; }
+            s_dyx[j] = a0; s_dy[j] = a1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
     const float m = (float)n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
@@ -263,16 +337,17 @@ __global__ void k_bn_bwd_apply(int64_t n, int F, float *d, const float *xhat, co
     }
 }
 
-// Weight and bias gradient of one Dense layer over row chunk blockIdx.z: part[chunk * pstride + i * n_out + j] = sum_r H'[r, i] DZ[r, j]
+// Weight and bias gradient of one Dense layer over one row chunk: part[chunk * pstride + i * n_out + j] = sum_r H'[r, i] DZ[r, j]
 // with H' = [H | 1] (row i = n_in is the bias gradient: dW and db are adjacent in the gradient vector).  16 x 16 outputs per
-// block, 64 rows staged per step.
-__global__ void __launch_bounds__(256) k_wgrad(int64_t n, int n_in, int n_out, const float *H, const float *DZ, float *part, int64_t pstride,
-                                               int64_t rows_per_block)
+// block, 64 rows staged per step.  lds: 2 x 64 x 17 floats.
+__device__ __forceinline__ void wgrad_block(int bx, int by, int bz, int64_t n, int n_in, int n_out, const float *__restrict__ H,
+                                            const float *__restrict__ DZ, float *part, int64_t pstride, int64_t rows_per_block, float *lds)
 {
-    __shared__ float sh[64][17], sz[64][17];
+    float (*sh)[17] = reinterpret_cast<float (*)[17]>(lds);
+    float (*sz)[17] = reinterpret_cast<float (*)[17]>(lds + 64 * 17);
     const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-    const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
-    const int64_t r0 = (int64_t)blockIdx.z * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const int i0 = bx * 16, j0 = by * 16;
+    const int64_t r0 = (int64_t)bz * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     float acc = 0.0f;
     for (int64_t r = r0; r < r1; r += 64) {
 #pragma unroll
@@ -287,18 +362,17 @@ __global__ void __launch_bounds__(256) k_wgrad(int64_t n, int n_in, int n_out, c
         for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(sh[q][ti], sz[q][tj], acc);
         __syncthreads();
     }
-    if (i0 + ti <= n_in && j0 + tj < n_out) part[(size_t)blockIdx.z * pstride + (size_t)(i0 + ti) * n_out + j0 + tj] = acc;
+    if (i0 + ti <= n_in && j0 + tj < n_out) part[(size_t)bz * pstride + (size_t)(i0 + ti) * n_out + j0 + tj] = acc;
 }
 
 // d h_in = d z . W^T, then (fused) the way back through what produced h_in: Dropout (keep != NULL) and the previous layer's
 // activation (act >= 0: d <- d * act'(a_prev)).  R rows of d z staged in LDS, one thread per column of h_in, as k_dense.
 template <int R>
-__global__ void __launch_bounds__(256) k_dense_bwd(int64_t n, int n_out, int n_out_pad, int n_in, const float *__restrict__ DZ,
-                                                   const float *__restrict__ WT, const uint8_t *__restrict__ keep, float rate,
-                                                   const float *__restrict__ a_prev, int act, float *__restrict__ dprev)
+__device__ __forceinline__ void dense_bwd_block(int64_t bid, int64_t n, int n_out, int n_out_pad, int n_in, const float *__restrict__ DZ,
+                                                const float *__restrict__ WT, const uint8_t *__restrict__ keep, float rate,
+                                                const float *__restrict__ a_prev, int act, float *__restrict__ dprev, float *xs)
 {
-    extern __shared__ __attribute__((aligned(16))) float xs[];
-    const int64_t i0 = (int64_t)blockIdx.x * R;
+    const int64_t i0 = bid * R;
     for (int t = threadIdx.x; t < R * n_out_pad; t += blockDim.x) {
         const int r = t / n_out_pad, k = t - r * n_out_pad;
         xs[t] = (k < n_out && i0 + r < n) ? DZ[(i0 + r) * n_out + k] : 0.0f;
@@ -338,57 +412,98 @@ __global__ void __launch_bounds__(256) k_dense_bwd(int64_t n, int n_out, int n_o
     }
 }
 
-// The concat of one body (reference GNN/GNN.py:223-239) in one pass: [state | node labels | aggregated states | aggregated labels |
-// aggregated arc labels].  Everything but the state columns and their aggregate is loop-invariant and comes from the template.
-// Dropout in front of the first Dense layer (rate != 0) is applied on the way out.
-__global__ void k_train_input(int64_t n, int in_s, int Ds, int c_aggs, const float *__restrict__ tmpl, const float *__restrict__ state,
-                              const int32_t *__restrict__ indptr, const int32_t *__restrict__ adj_src, const float *__restrict__ adj_w,
-                              float rate, const uint8_t *mask_in, uint64_t seed, uint8_t *keep, float *__restrict__ inp)
+// One Dense layer of the backward pass in one launch: the blocks of the weight / bias gradient (first wg_blocks ids: the heavier
+// ones) and the blocks of d h_in run side by side; both read d z, neither reads the other's result.
+struct LayerBwd {
+    int64_t n, rows_per_block, pstride;
+    int n_in, n_out, n_out_pad, act, wg_bx, wg_by, wg_blocks;
+    float rate;
+    const float *H, *DZ, *WT, *a_prev;
+    const uint8_t *keep;
+    float *part, *dprev;
+};
+
+template <int R>
+__global__ void __launch_bounds__(256) k_layer_bwd(const LayerBwd p)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * in_s) return;
-    const int64_t r = i / in_s;
-    const int c = (int)(i - r * in_s);
-    float v;
-    if (c < Ds) v = state[r * Ds + c];
-    else if (c >= c_aggs && c < c_aggs + Ds) {
-        const int cc = c - c_aggs;
-        v = 0.0f;
-        for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) v = __builtin_fmaf(adj_w[e], state[(int64_t)adj_src[e] * Ds + cc], v);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < p.wg_blocks) {
+        const int id = blockIdx.x, bx = id % p.wg_bx, by = (id / p.wg_bx) % p.wg_by, bz = id / (p.wg_bx * p.wg_by);
+        wgrad_block(bx, by, bz, p.n, p.n_in, p.n_out, p.H, p.DZ, p.part, p.pstride, p.rows_per_block, lds);
     } else
-        v = tmpl[i];
-    if (rate != 0.0f) {
-        const float rr = fabsf(rate);
-        uint8_t kp;
-        if (mask_in) kp = mask_in[i] != 0;
-        else kp = ((mix64(seed ^ mix64((uint64_t)i)) >> 40) * (1.0f / 16777216.0f)) >= rr;
-        keep[i] = kp;
-        if (rate < 0.0f) {
-            float a, b, ap;
-            alpha_dropout_coeffs(rr, &a, &b, &ap);
-            v = a * (kp ? v : ap) + b;
-        } else
-            v = kp ? v / (1.0f - rate) : 0.0f;
-    }
-    inp[i] = v;
+        dense_bwd_block<R>((int64_t)blockIdx.x - p.wg_blocks, p.n, p.n_out, p.n_out_pad, p.n_in, p.DZ, p.WT, p.keep, p.rate, p.a_prev, p.act, p.dprev, lds);
 }
 
-// condition() of the training-mode loop (reference GNN/GNN.py:202-220), one thread per node, ascending-feature sums as k_check
-__global__ void k_train_check(int64_t n, int d, const float *s, const float *so, float thr, int *flag)
+// The concat of one body (reference GNN/GNN.py:223-239) in one pass: [state | node labels | aggregated states | aggregated labels |
+// aggregated arc labels].  Everything but the state columns and their aggregate is loop-invariant and comes from the template.
+// Dropout in front of the first Dense layer (rate != 0) is applied on the way out.  The thread of column 0 also evaluates the
+// while-condition of THIS body for its node (reference GNN/GNN.py:202-220: condition(state, state_old), ascending-feature sums as
+// k_check; so == NULL: ones) and raises the body's gate.
+__global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds, int c_aggs, const float *__restrict__ tmpl, const float *__restrict__ state,
+                                                     const int32_t *__restrict__ indptr, const int32_t *__restrict__ adj_src,
+                                                     const float *__restrict__ adj_w, float rate, const uint8_t *mask_in, uint64_t seed, uint8_t *keep,
+                                                     float *__restrict__ inp, const float *__restrict__ so, float thr, int *flag)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0;
-    if (i < n) {
-        float dist = 0.0f, nrm = 0.0f;
-        for (int c = 0; c < d; ++c) {
-            const float o = so ? so[i * d + c] : 1.0f;
-            const float df = s[i * d + c] - o;
-            dist = dist + df * df;
-            nrm = nrm + o * o;
+    if (i < n * in_s) {
+        const int64_t r = i / in_s;
+        const int c = (int)(i - r * in_s);
+        float v;
+        if (c < Ds) v = state[r * Ds + c];
+        else if (c >= c_aggs && c < c_aggs + Ds) {
+            const int cc = c - c_aggs;
+            v = 0.0f;
+            for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) v = __builtin_fmaf(adj_w[e], state[(int64_t)adj_src[e] * Ds + cc], v);
+        } else
+            v = tmpl[i];
+        if (rate != 0.0f) {
+            const float rr = fabsf(rate);
+            uint8_t kp;
+            if (mask_in) kp = mask_in[i] != 0;
+            else kp = ((mix64(seed ^ mix64((uint64_t)i)) >> 40) * (1.0f / 16777216.0f)) >= rr;
+            keep[i] = kp;
+            if (rate < 0.0f) {
+                float a, b, ap;
+                alpha_dropout_coeffs(rr, &a, &b, &ap);
+                v = a * (kp ? v : ap) + b;
+            } else
+                v = kp ? v / (1.0f - rate) : 0.0f;
         }
-        f = __fsqrt_rn(dist) > thr * __fsqrt_rn(nrm);
+        inp[i] = v;
+        if (c == 0) {
+            float dist = 0.0f, nrm = 0.0f;
+            for (int q = 0; q < Ds; ++q) {
+                const float o = so ? so[r * Ds + q] : 1.0f;
+                const float df = state[r * Ds + q] - o;
+                dist = dist + df * df;
+                nrm = nrm + o * o;
+            }
+            f = __fsqrt_rn(dist) > thr * __fsqrt_rn(nrm);
+        }
     }
     if (__any(f) && (threadIdx.x & 63) == 0) gnn_flag_raise(flag);
+}
+
+// End of one body of the backward pass in one launch.  Blocks < sg_blocks: aggregated_states = Adjacency^T . state  =>
+// d state[r] = d inp[r, :Ds] + sum over arcs (r -> dst) of w * d inp[dst, c_aggs:] (own-state columns of the concat + the transposed
+// aggregation over the by-source CSR).  The other blocks: the net's gradient vector += this call's chunk partials (sum_parts_block).
+__global__ void __launch_bounds__(256) k_state_grad_sum(int sg_blocks, int64_t n, int Ds, int in_s, int c_aggs, const float *__restrict__ d_inp,
+                                                        const int32_t *__restrict__ sip, const int32_t *__restrict__ sdst, const float *__restrict__ sw,
+                                                        float *__restrict__ d_state, int parts, int64_t count, const float *part, float *out)
+{
+    __shared__ float sp[256];
+    if ((int)blockIdx.x >= sg_blocks) {
+        sum_parts_block(blockIdx.x - sg_blocks, parts, count, part, out, sp);
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * Ds) return;
+    const int64_t r = t / Ds;
+    const int c = (int)(t - r * Ds);
+    float acc = 0.0f;
+    for (int32_t e = sip[r]; e < sip[r + 1]; ++e) acc = __builtin_fmaf(sw[e], d_inp[(int64_t)sdst[e] * in_s + c_aggs + c], acc);
+    d_state[t] = d_inp[r * in_s + c] + acc;
 }
 
 __global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
@@ -409,20 +524,6 @@ __global__ void k_scatter_rows(int64_t m, const int32_t *rows, const float *d_fe
     const int64_t q = t / Ds;
     const int c = (int)(t - q * Ds);
     d_state[(int64_t)rows[q] * Ds + c] = d_feats[q * wf + c];
-}
-
-// aggregated_states = Adjacency^T . state  =>  d state[r] = d inp[r, :Ds] + sum over arcs (r -> dst) of w * d inp[dst, c_aggs:]:
-// own-state columns of the concat + the transposed aggregation over the by-source CSR, in one pass
-__global__ void k_state_grad(int64_t n, int Ds, int in_s, int c_aggs, const float *__restrict__ d_inp, const int32_t *__restrict__ sip,
-                             const int32_t *__restrict__ sdst, const float *__restrict__ sw, float *__restrict__ d_state)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * Ds) return;
-    const int64_t r = t / Ds;
-    const int c = (int)(t - r * Ds);
-    float acc = 0.0f;
-    for (int32_t e = sip[r]; e < sip[r + 1]; ++e) acc = __builtin_fmaf(sw[e], d_inp[(int64_t)sdst[e] * in_s + c_aggs + c], acc);
-    d_state[t] = d_inp[r * in_s + c] + acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -465,10 +566,24 @@ struct TrainArena {
         }
         return pinned;
     }
+    // pinned staging for the small per-step uploads (targets, sample weights, NodeGraph CSR): packed by the host, one transfer
+    void *staging = nullptr;
+    size_t staging_bytes = 0;
+    void *stage(size_t bytes)
+    {
+        if (bytes > staging_bytes) {
+            if (staging) (void)hipHostFree(staging);
+            staging = nullptr; staging_bytes = 0;
+            if (hipHostMalloc(&staging, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+            staging_bytes = bytes;
+        }
+        return staging;
+    }
     ~TrainArena()
     {
         for (Slab &s : slabs) (void)hipFree(s.p);
         if (pinned) (void)hipHostFree(pinned);
+        if (staging) (void)hipHostFree(staging);
     }
 };
 
@@ -514,7 +629,17 @@ struct Net {
 
 inline unsigned elementwise_grid(int64_t total) { return (unsigned)std::min<int64_t>(std::max<int64_t>(1, (total + 255) / 256), 2048); }
 
-int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host, int max_calls)
+// floats of zero-initialised memory a Net needs: the gradient vector and the BatchNormalization statistics of every call
+inline size_t net_zero_floats(const gnn_mlp *m, int max_calls)
+{
+    size_t t = 0;
+    for (int l = 0; l < m->n_layers; ++l) t += (size_t)m->dims[l] * m->dims[l + 1] + (size_t)m->dims[l + 1];
+    if (m->has_bn) t += (size_t)2 * m->dims.back() + (size_t)std::max(1, max_calls) * 2 * m->dims.back();
+    return (t + 63) & ~(size_t)63;
+}
+
+// zero_mem: net_zero_floats() floats the caller has zeroed (one memset for everything a step needs zeroed)
+int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float *rates, const float *bn_gamma_beta_host, int max_calls, float *zero_mem)
 {
     net.m = m;
     net.max_calls = max_calls;
@@ -522,10 +647,10 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
     net.rate.assign(rates, rates + L + 1);
     net.WT.assign(L, nullptr);
     size_t off = 0;
+    int rc;
     for (int l = 0; l < L; ++l) {
         const int ni = m->dims[l], no = m->dims[l + 1];
-        int rc = buf.get(&net.WT[l], (size_t)ni * no);
-        if (rc) return rc;
+        if ((rc = buf.get(&net.WT[l], (size_t)ni * no))) return rc;
         hipLaunchKernelGGL(k_transpose, cdiv((int64_t)ni * no, 256), 256, 0, st, ni, no, m->W[l], net.WT[l]);
         HIPCHK(hipGetLastError());
         net.g_off.push_back(off); off += (size_t)ni * no;
@@ -533,21 +658,18 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
     }
     if (m->has_bn) {
         const int F = m->dims.back();
-        int rc = buf.get(&net.gamma, (size_t)2 * F);
-        if (rc) return rc;
-        net.beta = net.gamma + F;
         // gamma | beta: the caller's arrays, or (NULL) the MLP's own device copy (the one the device-side optimizer updates)
-        if (bn_gamma_beta_host) HIPCHK(hipMemcpyAsync(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice, st));
-        else { net.gamma = m->bn_raw; net.beta = m->bn_raw + F; }
-        if ((rc = buf.get(&net.stats_all, (size_t)std::max(1, max_calls) * 2 * F))) return rc;
-        HIPCHK(hipMemsetAsync(net.stats_all, 0, sizeof(float) * (size_t)std::max(1, max_calls) * 2 * F, st));
+        if (bn_gamma_beta_host) {
+            if ((rc = buf.get(&net.gamma, (size_t)2 * F))) return rc;
+            net.beta = net.gamma + F;
+            HIPCHK(hipMemcpyAsync(net.gamma, bn_gamma_beta_host, sizeof(float) * 2 * F, hipMemcpyHostToDevice, st));
+        } else { net.gamma = m->bn_raw; net.beta = m->bn_raw + F; }
         net.g_off.push_back(off); off += F;
         net.g_off.push_back(off); off += F;
+        net.stats_all = zero_mem + off;
     }
     net.g_total = off;
-    int rc = buf.get(&net.grads, off);
-    if (rc) return rc;
-    HIPCHK(hipMemsetAsync(net.grads, 0, std::max<size_t>(off, 1) * sizeof(float), st));
+    net.grads = zero_mem;
     return GNN_OK;
 }
 
@@ -602,8 +724,9 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
             const int parts = (int)cdiv(n, rpb);
             float *part = nullptr;
             if ((rc = buf.get(&part, (size_t)parts * 2 * F))) return rc;
-            hipLaunchKernelGGL(k_bn_stats, dim3(cdiv(F, 32), parts), 256, 0, st, n, F, h, part, rpb);
-            hipLaunchKernelGGL(k_bn_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, h, part, parts, rpb, m->eps, net.gamma,
+            const int cs = column_shift(F);
+            hipLaunchKernelGGL(k_bn_stats, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, h, part, rpb);
+            hipLaunchKernelGGL(k_bn_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, h, part, parts, rpb, m->eps, net.gamma,
                                net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
         }
@@ -613,9 +736,18 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
     return GNN_OK;
 }
 
+// what follows the last layer of net_state's backward pass in the same launch as the sum of the chunk partials (k_state_grad_sum)
+struct StateGradJob {
+    int64_t N;
+    int Ds, in_s, c_aggs;
+    const int32_t *sip, *sdst;
+    const float *sw;
+    float *d_state;               // out: d loss / d state of the body's input
+};
+
 // back-propagation through one Sequential: d is d loss / d y on entry ([n, dims.back()], overwritten); on return *dx_out is
-// d loss / d x ([n, dims[0]]); weight gradients are ADDED into net.grads (one k_sum_parts over the call's chunk partials)
-int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d, float **dx_out)
+// d loss / d x ([n, dims[0]]); weight gradients are ADDED into net.grads (one sum over the call's chunk partials)
+int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d, float **dx_out, const StateGradJob *job = nullptr)
 {
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
@@ -636,11 +768,11 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
     // the derivative of the last activation rides on the BatchNormalization pass when nothing sits between them
     bool last_act_done = false;
     if (m->has_bn) {
-        const int F = m->dims.back();
+        const int F = m->dims.back(), cs = column_shift(F);
         float *p_dyx = net.part + net.g_off[2 * L], *p_dy = net.part + net.g_off[2 * L + 1];
         const bool fuse = net.rate[L] == 0.0f && act_last != GNN_ACT_SOFTMAX;
-        hipLaunchKernelGGL(k_colreduce2, dim3(cdiv(F, 32), parts), 256, 0, st, n, F, d, c.xhat, p_dyx, p_dy, ps, rpb);
-        hipLaunchKernelGGL(k_bn_bwd_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, d, c.xhat, net.gamma, c.stats, m->eps,
+        hipLaunchKernelGGL(k_colreduce2, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, d, c.xhat, p_dyx, p_dy, ps, rpb);
+        hipLaunchKernelGGL(k_bn_bwd_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps,
                            p_dyx, p_dy, ps, parts, c.a[L - 1], fuse ? act_last : -1);
         HIPCHK(hipGetLastError());
         last_act_done = fuse;
@@ -663,22 +795,32 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         const int ni = m->dims[l], no = m->dims[l + 1];
         float *dprev = nullptr;
         if ((rc = buf.get(&dprev, (size_t)n * ni))) return rc;
-        hipLaunchKernelGGL(k_wgrad, dim3(cdiv(ni + 1, 16), cdiv(no, 16), parts), 256, 0, st, n, ni, no, c.hin[l], d, net.part + net.g_off[2 * l], ps, rpb);
-        // d h_in = d z . W^T, back through Dropout l and (l > 0) the activation of layer l - 1
+        // weight + bias gradient tiles and d h_in = d z . W^T (back through Dropout l and, l > 0, the activation of layer l - 1) in one launch
         const int act_prev = l > 0 ? m->acts[l - 1] : -1;
         const bool prev_sm = act_prev == GNN_ACT_SOFTMAX;
         constexpr int R = 8;
-        const int no_pad = (no + 3) & ~3;
-        const size_t lds = sizeof(float) * R * no_pad;
+        LayerBwd p;
+        p.n = n; p.rows_per_block = rpb; p.pstride = ps;
+        p.n_in = ni; p.n_out = no; p.n_out_pad = (no + 3) & ~3; p.act = prev_sm ? -1 : act_prev;
+        p.wg_bx = (int)cdiv(ni + 1, 16); p.wg_by = (int)cdiv(no, 16); p.wg_blocks = p.wg_bx * p.wg_by * parts;
+        p.rate = net.rate[l];
+        p.H = c.hin[l]; p.DZ = d; p.WT = net.WT[l]; p.a_prev = l > 0 ? c.a[l - 1] : nullptr;
+        p.keep = net.rate[l] != 0.0f ? c.keep[l] : nullptr;
+        p.part = net.part + net.g_off[2 * l]; p.dprev = dprev;
+        const size_t lds = std::max(sizeof(float) * R * p.n_out_pad, sizeof(float) * 2 * 64 * 17);
         if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer width %d too large", no);
-        hipLaunchKernelGGL((k_dense_bwd<R>), cdiv(n, R), std::min(256, ((ni + 63) / 64) * 64), lds, st, n, no, no_pad, ni, d, net.WT[l],
-                           net.rate[l] != 0.0f ? c.keep[l] : (const uint8_t *)nullptr, net.rate[l], l > 0 ? c.a[l - 1] : (const float *)nullptr,
-                           prev_sm ? -1 : act_prev, dprev);
+        hipLaunchKernelGGL((k_layer_bwd<R>), (unsigned)(p.wg_blocks + cdiv(n, R)), 256, lds, st, p);
         if (prev_sm) hipLaunchKernelGGL(k_act_bwd, cdiv(n, 256), 256, 0, st, n, ni, dprev, c.a[l - 1], act_prev);
         HIPCHK(hipGetLastError());
         d = dprev;
     }
-    hipLaunchKernelGGL(k_sum_parts, cdiv((int64_t)net.g_total, 256), 256, 0, st, parts, (int64_t)net.g_total, net.part, net.grads);
+    const unsigned sum_blocks = cdiv((int64_t)net.g_total, 64);
+    if (job && job->N > 0) {
+        const int sg = (int)cdiv(job->N * job->Ds, 256);
+        hipLaunchKernelGGL(k_state_grad_sum, sg + sum_blocks, 256, 0, st, sg, job->N, job->Ds, job->in_s, job->c_aggs, d, job->sip, job->sdst, job->sw,
+                           job->d_state, parts, (int64_t)net.g_total, net.part, net.grads);
+    } else
+        hipLaunchKernelGGL(k_sum_parts, sum_blocks, 256, 0, st, parts, (int64_t)net.g_total, net.part, net.grads);
     HIPCHK(hipGetLastError());
     *dx_out = d;
     return GNN_OK;
@@ -777,24 +919,34 @@ __global__ void __launch_bounds__(256) k_loss_rows(int kind, int64_t n, int T, c
     if (threadIdx.x == 0) loss_part[blockIdx.x] = sl[0];
 }
 
-// GNNgraphBased readout inside the step: og = NodeGraph^T . out_nodes (GNN.py:331-332) over the CSR by graph, and its transpose
-__global__ void k_graph_out(int n_graphs, int T, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w, const float *out_nodes, float *og)
+// GNNgraphBased readout inside the step: og = NodeGraph^T . out_nodes (GNN.py:331-332) over the CSR by graph, one wave per graph
+// (lanes take every 64th entry, then a fixed butterfly adds the lanes), and its transpose
+__global__ void __launch_bounds__(256) k_graph_out(int n_graphs, int T, const int32_t *__restrict__ ng_indptr, const int32_t *__restrict__ ng_node,
+                                                   const float *__restrict__ ng_w, const float *__restrict__ out_nodes, float *og)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_graphs * T) return;
-    const int gi = t / T, c = t - gi * T;
-    float acc = 0.0f;
-    for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e) acc += ng_w[e] * out_nodes[(int64_t)ng_node[e] * T + c];
-    og[t] = acc;
+    const int gi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (gi >= n_graphs) return;
+    const int e0 = ng_indptr[gi], e1 = ng_indptr[gi + 1];
+    for (int c = 0; c < T; ++c) {
+        float acc = 0.0f;
+        for (int e = e0 + lane; e < e1; e += 64) acc += ng_w[e] * out_nodes[(int64_t)ng_node[e] * T + c];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) og[gi * T + c] = acc;
+    }
 }
 
-__global__ void k_graph_out_bwd(int n_graphs, int T, const int32_t *ng_indptr, const int32_t *ng_node, const float *ng_w, const float *d_og, float *d_nodes)
+// d out_nodes[node, c] = w * d og[graph of the entry, c]: one thread per entry and column, the entry's graph by bisection
+__global__ void k_graph_out_bwd(int n_graphs, int T, const int32_t *__restrict__ ng_indptr, const int32_t *__restrict__ ng_node,
+                                const float *__restrict__ ng_w, const float *__restrict__ d_og, float *d_nodes)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_graphs * T) return;
-    const int gi = t / T, c = t - gi * T;
+    const int ne = ng_indptr[n_graphs];
+    if (t >= ne * T) return;
+    const int e = t / T, c = t - e * T;
+    int lo = 0, hi = n_graphs;                 // largest lo with ng_indptr[lo] <= e
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ng_indptr[mid] <= e) lo = mid; else hi = mid; }
     // a node belongs to one graph: the adds of different threads do not meet (atomic only so that a malformed NodeGraph stays defined)
-    for (int e = ng_indptr[gi]; e < ng_indptr[gi + 1]; ++e) atomicAdd(&d_nodes[(int64_t)ng_node[e] * T + c], ng_w[e] * d_og[t]);
+    atomicAdd(&d_nodes[(int64_t)ng_node[e] * T + c], ng_w[e] * d_og[lo * T + c]);
 }
 
 // d_nodes[r, c] += d_inp[r, c_nodes + c] + via[r, c]   (direct label columns of the concat + transposed aggregated_nodes)
@@ -942,7 +1094,19 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     Buf &buf = cx->buf;
     Net &ns = cx->ns, &no_ = cx->no_;
     int rc;
-    if ((rc = net_setup(st, buf, ns, l->st, dropout_state, bn_state, l->max_iter)) || (rc = net_setup(st, buf, no_, l->ou, dropout_output, bn_output, 1))) return rc;
+    // everything the step needs zeroed, in one block and one memset: gradients and BatchNormalization statistics of both nets, the
+    // iteration gates, the template of the concat
+    const int max_iter = l->max_iter;
+    const size_t flag_words = (size_t)(max_iter + 1) * GNN_FLAG_WORDS;
+    const size_t z_s = net_zero_floats(l->st, max_iter), z_o = net_zero_floats(l->ou, 1), z_f = (flag_words + 63) & ~(size_t)63;
+    const size_t z_total = z_s + z_o + z_f + (size_t)N * l->in_s;
+    float *zero_mem = nullptr;
+    if ((rc = buf.get(&zero_mem, z_total))) return rc;
+    HIPCHK(hipMemsetAsync(zero_mem, 0, sizeof(float) * std::max<size_t>(1, z_total), st));
+    if ((rc = net_setup(st, buf, ns, l->st, dropout_state, bn_state, max_iter, zero_mem)) ||
+        (rc = net_setup(st, buf, no_, l->ou, dropout_output, bn_output, 1, zero_mem + z_s))) return rc;
+    int *flags = reinterpret_cast<int *>(zero_mem + z_s + z_o);
+    float *tmpl = zero_mem + z_s + z_o + z_f;
     // Adjacency by source for the transposed aggregation of the backward pass: the caller's arrays, or (NULL) the graph's
     // own copy, built once from its CSR by destination (a stable counting sort by source keeps destinations ascending)
     if (src_indptr) {
@@ -972,9 +1136,6 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     }
 
     // template of the concat with the loop-invariant columns filled in (GNN.py:259, :263)
-    float *tmpl = nullptr;
-    if ((rc = buf.get(&tmpl, (size_t)N * in_s))) return rc;
-    HIPCHK(hipMemsetAsync(tmpl, 0, sizeof(float) * std::max<size_t>(1, (size_t)N * in_s), st));
     const int c_nodes = Ds, c_aggs = Ds + NLc, c_aggn = c_aggs + Ds, c_agga = c_aggn + NLc;
     if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
     if (l->D) {
@@ -997,24 +1158,16 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     }
 
     // ---- while condition: state <- net_state(concat), training mode (GNN.py:271 with training=True) ----------------------
-    // Gate i = condition(state_i, state_{i-1}) decides whether body i runs.  The bodies are enqueued TRAIN_CHUNK at a time without
-    // waiting for their gates; the host then reads the gates of the chunk in one synchronisation, and the bodies enqueued
-    // beyond a closed gate (at most TRAIN_CHUNK - 1 of them) are dropped: their results are never read.
-    const int max_iter = l->max_iter;
-    int *flags = nullptr;
-    const size_t flag_words = (size_t)(max_iter + 1) * GNN_FLAG_WORDS;
-    if ((rc = buf.get(&flags, flag_words))) return rc;
-    HIPCHK(hipMemsetAsync(flags, 0, sizeof(int) * flag_words, st));
+    // Gate i = condition(state_i, state_{i-1}) decides whether body i runs; it is evaluated by the body's own first kernel.  The
+    // bodies are enqueued TRAIN_CHUNK at a time without waiting for their gates; the host then reads the gates of the chunk in one
+    // synchronisation, and the bodies enqueued from a closed gate on (at most TRAIN_CHUNK of them) are dropped: their results are
+    // never read.
     int *hflags = static_cast<int *>(arena->host(std::max<size_t>(sizeof(int) * flag_words, 4096)));
     if (!hflags) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
     std::vector<float *> states;                       // states[i]: the state body i reads; states[0] is read in place
     states.push_back(const_cast<float *>(l->D ? l->state_init : g->nodes));
-    auto check = [&](int i) {
-        if (N) hipLaunchKernelGGL(k_train_check, cdiv(N, 256), 256, 0, st, N, Ds, states[i], i ? states[i - 1] : (const float *)nullptr, l->thr,
-                                  flags + (size_t)i * GNN_FLAG_WORDS);
-    };
-    check(0);
     int enq = 0, k = -1;
+    if (N == 0 || max_iter == 0) k = 0;                // no node can raise a gate / no body allowed
     while (k < 0) {
         const int target = std::min(max_iter, enq + TRAIN_CHUNK);
         for (; enq < target; ++enq) {
@@ -1025,18 +1178,18 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
             if (r0 != 0.0f && (rc = buf.get(&keep0, (size_t)N * in_s))) return rc;
             const uint8_t *mk = d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)enq : nullptr;
             const uint64_t sd = seed + 7919ull * (uint64_t)(enq + 1);
-            if (N) hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
-                                      g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp);
+            // the input kernel of body i also evaluates gate i = condition(state_i, state_{i-1})
+            hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
+                               g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp, enq ? states[enq - 1] : (const float *)nullptr, l->thr,
+                               flags + (size_t)enq * GNN_FLAG_WORDS);
             HIPCHK(hipGetLastError());
             cx->caches.emplace_back();
             if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y))) return rc;
             states.push_back(y);
-            check(enq + 1);
         }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int) * (size_t)(enq + 1) * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int) * (size_t)enq * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        for (int i = 0; i <= enq && k < 0; ++i) {
+        for (int i = 0; i < enq && k < 0; ++i) {       // gates 0 .. enq - 1 are known; gate enq belongs to the next chunk's first body
             int any = 0;
             for (int w = 0; w < GNN_FLAG_WORDS; w += GNN_FLAG_STRIDE) any |= hflags[(size_t)i * GNN_FLAG_WORDS + w];
             if (!any) k = i;
@@ -1141,14 +1294,11 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
         }
     }
     for (int it = k - 1; it >= 0; --it) {
-        // net_backward consumes d_state (d loss / d state_{it+1}) in place; k_state_grad then writes d loss / d state_it into a new buffer
+        // net_backward consumes d_state (d loss / d state_{it+1}) in place; its last launch also writes d loss / d state_it into a new buffer
         float *d_inp = nullptr, *d_prev = nullptr;
-        if ((rc = net_backward(st, buf, ns, cx->caches[it], d_state, &d_inp))) return rc;
         if ((rc = buf.get(&d_prev, (size_t)N * Ds))) return rc;
-        if (N) {
-            hipLaunchKernelGGL(k_state_grad, cdiv(N * Ds, 256), 256, 0, st, N, Ds, in_s, c_aggs, d_inp, cx->d_sip, cx->d_sdst, cx->d_sw, d_prev);
-            HIPCHK(hipGetLastError());
-        }
+        const StateGradJob job{N, Ds, in_s, c_aggs, cx->d_sip, cx->d_sdst, cx->d_sw, d_prev};
+        if ((rc = net_backward(st, buf, ns, cx->caches[it], d_state, &d_inp, &job))) return rc;
         d_state = d_prev;
         if (want_arcs && N) {
             hipLaunchKernelGGL(k_add_cols, cdiv(N * AL, 256), 256, 0, st, N, AL, d_inp, in_s, c_agga, d_aa);
@@ -1162,9 +1312,8 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
     }
     HIPCHK(hipMemcpyAsync(grads_state, ns.grads, sizeof(float) * ns.g_total, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(grads_output, no_.grads, sizeof(float) * no_.g_total, hipMemcpyDeviceToHost, st));
-    if (bn_batch_state && l->st->has_bn)
-        for (int it = 0; it < k; ++it)
-            HIPCHK(hipMemcpyAsync(bn_batch_state + (size_t)it * 2 * Ds, cx->caches[it].stats, sizeof(float) * 2 * Ds, hipMemcpyDeviceToHost, st));
+    if (bn_batch_state && l->st->has_bn && k > 0)      // the statistics of the calls are adjacent, in call order
+        HIPCHK(hipMemcpyAsync(bn_batch_state, ns.stats_all, sizeof(float) * (size_t)k * 2 * Ds, hipMemcpyDeviceToHost, st));
     if (bn_batch_output && l->ou->has_bn && M) HIPCHK(hipMemcpyAsync(bn_batch_output, cx->co.stats, sizeof(float) * 2 * T, hipMemcpyDeviceToHost, st));
     if (want_arcs && g->E) {
         if (M) hipLaunchKernelGGL(k_arc_grad_readout, cdiv(M * AL, 256), 256, 0, st, M, AL, l->edge_rows, d_feats, wf, 2 * (Ds + NLc), d_arcs);
@@ -1326,28 +1475,36 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
     const int64_t nt = n_targets;
     const unsigned lblocks = nt ? cdiv(nt, 256) : 0;
     double loss = 0.0;
-    if (nt) {
-        if ((rc = buf.get(&d_t, (size_t)nt * T)) || (rc = buf.get(&d_w, (size_t)nt)) || (rc = buf.get(&d_o, (size_t)nt * T)) || (rc = buf.get(&d_lp, (size_t)lblocks))) return rc;
-        HIPCHK(hipMemcpyAsync(d_t, targets, sizeof(float) * (size_t)nt * T, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_w, sample_weights, sizeof(float) * (size_t)nt, hipMemcpyHostToDevice, st));
-    }
     double *h_lp = static_cast<double *>(arena->host(std::max<size_t>(sizeof(double) * lblocks, 4096)));
     if (!h_lp) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
-    if (n_graphs > 0) {                            // GNNgraphBased: out = NodeGraph^T . out_nodes (GNN.py:331-332)
-        int32_t *d_ip = nullptr, *d_nd = nullptr;
-        float *d_nw = nullptr, *og = nullptr;
-        const int64_t ne = ng_indptr[n_graphs];
-        if ((rc = buf.get(&d_ip, (size_t)n_graphs + 1)) || (rc = buf.get(&d_nd, (size_t)ne)) || (rc = buf.get(&d_nw, (size_t)ne)) ||
-            (rc = buf.get(&og, (size_t)n_graphs * T)) || (rc = buf.get(&d_dnodes, (size_t)M * T))) return rc;
-        HIPCHK(hipMemcpyAsync(d_ip, ng_indptr, sizeof(int32_t) * ((size_t)n_graphs + 1), hipMemcpyHostToDevice, st));
-        if (ne) {
-            HIPCHK(hipMemcpyAsync(d_nd, ng_node, sizeof(int32_t) * (size_t)ne, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(d_nw, ng_w, sizeof(float) * (size_t)ne, hipMemcpyHostToDevice, st));
+    // the step's small inputs, packed into pinned memory and uploaded in one transfer: targets | sample weights | NodeGraph^T CSR
+    const int64_t ne = n_graphs > 0 ? ng_indptr[n_graphs] : 0;
+    auto pad4 = [](size_t words) { return (words + 63) & ~(size_t)63; };
+    const size_t o_t = 0, o_w = o_t + pad4((size_t)nt * T), o_ip = o_w + pad4((size_t)nt), o_nd = o_ip + pad4(n_graphs > 0 ? (size_t)n_graphs + 1 : 0),
+                 o_nw = o_nd + pad4((size_t)ne), up_words = o_nw + pad4((size_t)ne);
+    float *up = nullptr;
+    if (up_words) {
+        float *hs = static_cast<float *>(arena->stage(sizeof(float) * up_words));
+        if (!hs) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
+        if ((rc = buf.get(&up, up_words))) return rc;
+        if (nt) { memcpy(hs + o_t, targets, sizeof(float) * (size_t)nt * T); memcpy(hs + o_w, sample_weights, sizeof(float) * (size_t)nt); }
+        if (n_graphs > 0) {
+            memcpy(hs + o_ip, ng_indptr, sizeof(int32_t) * ((size_t)n_graphs + 1));
+            if (ne) { memcpy(hs + o_nd, ng_node, sizeof(int32_t) * (size_t)ne); memcpy(hs + o_nw, ng_w, sizeof(float) * (size_t)ne); }
         }
+        HIPCHK(hipMemcpyAsync(up, hs, sizeof(float) * up_words, hipMemcpyHostToDevice, st));
+        d_t = up + o_t; d_w = up + o_w;
+    }
+    if (nt && ((rc = buf.get(&d_o, (size_t)nt * T)) || (rc = buf.get(&d_lp, (size_t)lblocks)))) return rc;
+    if (n_graphs > 0) {                            // GNNgraphBased: out = NodeGraph^T . out_nodes (GNN.py:331-332)
+        const int32_t *d_ip = reinterpret_cast<const int32_t *>(up + o_ip), *d_nd = reinterpret_cast<const int32_t *>(up + o_nd);
+        const float *d_nw = up + o_nw;
+        float *og = nullptr;
+        if ((rc = buf.get(&og, (size_t)n_graphs * T)) || (rc = buf.get(&d_dnodes, (size_t)M * T))) return rc;
         HIPCHK(hipMemsetAsync(d_dnodes, 0, sizeof(float) * std::max<size_t>(1, (size_t)M * T), st));
-        hipLaunchKernelGGL(k_graph_out, cdiv((int64_t)n_graphs * T, 256), 256, 0, st, n_graphs, T, d_ip, d_nd, d_nw, cx->out_nodes, og);
+        hipLaunchKernelGGL(k_graph_out, cdiv(n_graphs, 4), 256, 0, st, n_graphs, T, d_ip, d_nd, d_nw, cx->out_nodes, og);
         hipLaunchKernelGGL(k_loss_rows, lblocks, 256, 0, st, loss_kind, nt, T, d_t, og, d_w, d_o, d_lp);
-        hipLaunchKernelGGL(k_graph_out_bwd, cdiv((int64_t)n_graphs * T, 256), 256, 0, st, n_graphs, T, d_ip, d_nd, d_nw, d_o, d_dnodes);
+        if (ne) hipLaunchKernelGGL(k_graph_out_bwd, cdiv(ne * T, 256), 256, 0, st, n_graphs, T, d_ip, d_nd, d_nw, d_o, d_dnodes);
         HIPCHK(hipGetLastError());
     } else if (nt) {
         hipLaunchKernelGGL(k_loss_rows, lblocks, 256, 0, st, loss_kind, nt, T, d_t, cx->out_nodes, d_w, d_o, d_lp);

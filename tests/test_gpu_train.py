@@ -534,7 +534,7 @@ def test_device_optimizer_matches_host_optimizer(opt_name, graph_based):
         set_seed(3)
         st = MLP(1 + 2 * 3, [8, 3], 'selu', 'glorot_normal', 'zeros')                       # BatchNormalization on (default)
         ou = MLP(3, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
-        opt = optimizers.Adam(0.01) if opt_name == 'Adam' else optimizers.SGD(0.05, momentum=0.9)
+        opt = optimizers.Adam(0.01) if opt_name == 'Adam' else optimizers.SGD(0.01, momentum=0.9)
         m = (GNNgraphBased if graph_based else GNNnodeBased)(net_state=st, net_output=ou, optimizer=opt, loss_function=losses.categorical_crossentropy,
                                                              loss_arguments=None, state_vect_dim=0, max_iteration=3, threshold=0.001, addressed_problem='c')
         m.device_optimizer = device_optimizer
@@ -550,7 +550,7 @@ def test_device_optimizer_matches_host_optimizer(opt_name, graph_based):
     assert dev.net_state._host_stale                       # nothing has been read back yet
     for net_h, net_d in ((host.net_state, dev.net_state), (host.net_output, dev.net_output)):
         for a, b in zip(net_h.get_weights(), net_d.get_weights()):
-            assert np.max(np.abs(a - b)) <= 2e-5 * max(1.0, np.max(np.abs(a)))
+            assert np.max(np.abs(a - b)) <= 5e-5 * max(1.0, np.max(np.abs(a)))       # float32 slots on the device, float64 in NumPy
     assert not dev.net_state._host_stale
     # the refreshed host copies and the device agree: an inference Loop after set_weights(get_weights()) gives the same output
     k0, _, out0 = dev.Loop(batch)
