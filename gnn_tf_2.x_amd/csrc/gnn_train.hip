@@ -349,15 +349,22 @@ __device__ __forceinline__ void wgrad_block(int bx, int by, int bz, int64_t n, i
     const int i0 = bx * 16, j0 = by * 16;
     const int64_t r0 = (int64_t)bz * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     float acc = 0.0f;
-    for (int64_t r = r0; r < r1; r += 64) {
+    float hv[4], zv[4];
+    auto fetch = [&](int64_t r) {                  // this thread's share of the 64-row step at r, into registers
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t row = r + ti + 16 * q;
             const bool in = row < r1;
-            sh[ti + 16 * q][tj] = !in ? 0.0f : (i0 + tj < n_in ? H[row * n_in + i0 + tj] : (i0 + tj == n_in ? 1.0f : 0.0f));
-            sz[ti + 16 * q][tj] = (in && j0 + tj < n_out) ? DZ[row * n_out + j0 + tj] : 0.0f;
+            hv[q] = !in ? 0.0f : (i0 + tj < n_in ? H[row * n_in + i0 + tj] : (i0 + tj == n_in ? 1.0f : 0.0f));
+            zv[q] = (in && j0 + tj < n_out) ? DZ[row * n_out + j0 + tj] : 0.0f;
         }
+    };
+    if (r0 < r1) fetch(r0);
+    for (int64_t r = r0; r < r1; r += 64) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sh[ti + 16 * q][tj] = hv[q]; sz[ti + 16 * q][tj] = zv[q]; }
         __syncthreads();
+        if (r + 64 < r1) fetch(r + 64);            // the next step's loads fly during this step's products
 #pragma unroll 16
         for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(sh[q][ti], sz[q][tj], acc);
         __syncthreads();
@@ -367,8 +374,62 @@ __device__ __forceinline__ void wgrad_block(int bx, int by, int bz, int64_t n, i
 
 // d h_in = d z . W^T, then (fused) the way back through what produced h_in: Dropout (keep != NULL) and the previous layer's
 // activation (act >= 0: d <- d * act'(a_prev)).  R rows of d z staged in LDS, one thread per column of h_in, as k_dense.
+// Dense products of the training step, Y[r, j] = sum_k X[r, k] M[k, j] on R rows per block: 256 threads = CW output columns x KG
+// slices of the k range (CW = 2^cshift >= min(columns, 64)); every thread runs the fmaf chain of its slice (one to a few iterations
+// even for narrow layers: the loop over k is a chain of L2 round trips), the KG partial sums of an output are added in slice order
+// through LDS.  xs: R rows of X, padded to a multiple of 4 (zeros); ps: [KG][R][CW] partials.  fin(r, j, value) stores an output.
+template <int R, class Fin>
+__device__ __forceinline__ void dense_rows(int n_k, int n_k_pad, int n_cols, int cshift, const float *__restrict__ M, const float *xs, float *ps, Fin fin)
+{
+    const int CW = 1 << cshift, KG = 256 >> cshift;
+    const int c = threadIdx.x & (CW - 1), kg = threadIdx.x >> cshift;
+    const int slice = ((n_k + KG - 1) / KG + 3) & ~3;
+    const int k0 = kg * slice, k1 = k0 + slice < n_k ? k0 + slice : n_k;
+    for (int jb = 0; jb < n_cols; jb += CW) {
+        const int j = jb + c;
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+        if (j < n_cols) {
+            int k = k0;
+            for (; k + 4 <= k1; k += 4) {
+                const float w0 = M[(size_t)(k + 0) * n_cols + j], w1 = M[(size_t)(k + 1) * n_cols + j];
+                const float w2 = M[(size_t)(k + 2) * n_cols + j], w3 = M[(size_t)(k + 3) * n_cols + j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 x = *reinterpret_cast<const float4 *>(&xs[r * n_k_pad + k]);
+                    acc[r] = __builtin_fmaf(x.x, w0, acc[r]);
+                    acc[r] = __builtin_fmaf(x.y, w1, acc[r]);
+                    acc[r] = __builtin_fmaf(x.z, w2, acc[r]);
+                    acc[r] = __builtin_fmaf(x.w, w3, acc[r]);
+                }
+            }
+            for (; k < k1; ++k) {
+                const float wk = M[(size_t)k * n_cols + j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(xs[r * n_k_pad + k], wk, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ps[(kg * R + r) * CW + c] = acc[r];
+        __syncthreads();
+        if (j < n_cols)
+            for (int r = kg; r < R; r += KG) {
+                float v = ps[r * CW + c];
+                for (int g = 1; g < KG; ++g) v += ps[(g * R + r) * CW + c];
+                fin(r, j, v);
+            }
+        __syncthreads();
+    }
+}
+
+inline int dense_cshift(int cols) { int s = 2; while ((1 << s) < cols && s < 6) ++s; return s; }     // CW = 4 .. 64
+inline size_t dense_lds_bytes(int R, int k_pad) { return sizeof(float) * ((size_t)R * k_pad + (size_t)256 * R); }
+
+// d h_in = d z . W^T, then (fused) the way back through what produced h_in: Dropout (keep != NULL) and the previous layer's
+// activation (act >= 0: d <- d * act'(a_prev))
 template <int R>
-__device__ __forceinline__ void dense_bwd_block(int64_t bid, int64_t n, int n_out, int n_out_pad, int n_in, const float *__restrict__ DZ,
+__device__ __forceinline__ void dense_bwd_block(int64_t bid, int64_t n, int n_out, int n_out_pad, int n_in, int cshift, const float *__restrict__ DZ,
                                                 const float *__restrict__ WT, const uint8_t *__restrict__ keep, float rate,
                                                 const float *__restrict__ a_prev, int act, float *__restrict__ dprev, float *xs)
 {
@@ -378,45 +439,40 @@ __device__ __forceinline__ void dense_bwd_block(int64_t bid, int64_t n, int n_ou
         xs[t] = (k < n_out && i0 + r < n) ? DZ[(i0 + r) * n_out + k] : 0.0f;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < n_in; j += blockDim.x) {
-        float acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = 0.0f;
-        int k = 0;
-        for (; k + 4 <= n_out; k += 4) {
-            const float w0 = WT[(size_t)(k + 0) * n_in + j], w1 = WT[(size_t)(k + 1) * n_in + j];
-            const float w2 = WT[(size_t)(k + 2) * n_in + j], w3 = WT[(size_t)(k + 3) * n_in + j];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float4 x = *reinterpret_cast<const float4 *>(&xs[r * n_out_pad + k]);
-                acc[r] = __builtin_fmaf(x.x, w0, acc[r]);
-                acc[r] = __builtin_fmaf(x.y, w1, acc[r]);
-                acc[r] = __builtin_fmaf(x.z, w2, acc[r]);
-                acc[r] = __builtin_fmaf(x.w, w3, acc[r]);
-            }
-        }
-        for (; k < n_out; ++k) {
-            const float wk = WT[(size_t)k * n_in + j];
-#pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = __builtin_fmaf(xs[r * n_out_pad + k], wk, acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (i0 + r >= n) break;
-            const int64_t o = (i0 + r) * n_in + j;
-            float v = acc[r];
-            if (keep) v = dropout_grad(v, keep[o], rate);
-            if (act >= 0) v = v * act_grad(a_prev[o], act);
-            dprev[o] = v;
-        }
+    dense_rows<R>(n_out, n_out_pad, n_in, cshift, WT, xs, xs + R * n_out_pad, [&](int r, int j, float v) {
+        if (i0 + r >= n) return;
+        const int64_t o = (i0 + r) * n_in + j;
+        if (keep) v = dropout_grad(v, keep[o], rate);
+        if (act >= 0) v = v * act_grad(a_prev[o], act);
+        dprev[o] = v;
+    });
+}
+
+// a = act(h . W + b), training-mode forward of one Dense layer (softmax is applied by the caller)
+template <int R>
+__global__ void __launch_bounds__(256) k_dense_fwd(int64_t n, int n_in, int n_in_pad, int n_out, int cshift, const float *__restrict__ X,
+                                                   const float *__restrict__ W, const float *__restrict__ b, int act, float *__restrict__ Y)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int64_t i0 = (int64_t)blockIdx.x * R;
+    for (int t = threadIdx.x; t < R * n_in_pad; t += blockDim.x) {
+        const int r = t / n_in_pad, k = t - r * n_in_pad;
+        xs[t] = (k < n_in && i0 + r < n) ? X[(i0 + r) * n_in + k] : 0.0f;
     }
+    __syncthreads();
+    dense_rows<R>(n_in, n_in_pad, n_out, cshift, W, xs, xs + R * n_in_pad, [&](int r, int j, float v) {
+        if (i0 + r >= n) return;
+        v = v + b[j];
+        if (act != GNN_ACT_SOFTMAX) v = gnn_act(v, act);
+        Y[(i0 + r) * n_out + j] = v;
+    });
 }
 
 // One Dense layer of the backward pass in one launch: the blocks of the weight / bias gradient (first wg_blocks ids: the heavier
 // ones) and the blocks of d h_in run side by side; both read d z, neither reads the other's result.
 struct LayerBwd {
     int64_t n, rows_per_block, pstride;
-    int n_in, n_out, n_out_pad, act, wg_bx, wg_by, wg_blocks;
+    int n_in, n_out, n_out_pad, act, wg_bx, wg_by, wg_blocks, cshift;
     float rate;
     const float *H, *DZ, *WT, *a_prev;
     const uint8_t *keep;
@@ -431,7 +487,7 @@ __global__ void __launch_bounds__(256) k_layer_bwd(const LayerBwd p)
         const int id = blockIdx.x, bx = id % p.wg_bx, by = (id / p.wg_bx) % p.wg_by, bz = id / (p.wg_bx * p.wg_by);
         wgrad_block(bx, by, bz, p.n, p.n_in, p.n_out, p.H, p.DZ, p.part, p.pstride, p.rows_per_block, lds);
     } else
-        dense_bwd_block<R>((int64_t)blockIdx.x - p.wg_blocks, p.n, p.n_out, p.n_out_pad, p.n_in, p.DZ, p.WT, p.keep, p.rate, p.a_prev, p.act, p.dprev, lds);
+        dense_bwd_block<R>((int64_t)blockIdx.x - p.wg_blocks, p.n, p.n_out, p.n_out_pad, p.n_in, p.cshift, p.DZ, p.WT, p.keep, p.rate, p.a_prev, p.act, p.dprev, lds);
 }
 
 // The concat of one body (reference GNN/GNN.py:223-239) in one pass: [state | node labels | aggregated states | aggregated labels |
@@ -450,11 +506,25 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
         const int64_t r = i / in_s;
         const int c = (int)(i - r * in_s);
         float v;
+        bool skip = false;                         // Ds % 4 == 0: the thread of every fourth aggregate column gathers and writes four
         if (c < Ds) v = state[r * Ds + c];
         else if (c >= c_aggs && c < c_aggs + Ds) {
             const int cc = c - c_aggs;
             v = 0.0f;
-            for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) v = __builtin_fmaf(adj_w[e], state[(int64_t)adj_src[e] * Ds + cc], v);
+            if ((Ds & 3) == 0 && rate == 0.0f) {
+                skip = true;
+                if ((cc & 3) == 0) {
+                    float4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) {
+                        const float w = adj_w[e];
+                        const float4 x = *reinterpret_cast<const float4 *>(state + (int64_t)adj_src[e] * Ds + cc);
+                        a4.x = __builtin_fmaf(w, x.x, a4.x); a4.y = __builtin_fmaf(w, x.y, a4.y);
+                        a4.z = __builtin_fmaf(w, x.z, a4.z); a4.w = __builtin_fmaf(w, x.w, a4.w);
+                    }
+                    inp[i] = a4.x; inp[i + 1] = a4.y; inp[i + 2] = a4.z; inp[i + 3] = a4.w;
+                }
+            } else
+                for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) v = __builtin_fmaf(adj_w[e], state[(int64_t)adj_src[e] * Ds + cc], v);
         } else
             v = tmpl[i];
         if (rate != 0.0f) {
@@ -470,15 +540,27 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
             } else
                 v = kp ? v / (1.0f - rate) : 0.0f;
         }
-        inp[i] = v;
+        if (!skip) inp[i] = v;
         if (c == 0) {
             float dist = 0.0f, nrm = 0.0f;
-            for (int q = 0; q < Ds; ++q) {
-                const float o = so ? so[r * Ds + q] : 1.0f;
-                const float df = state[r * Ds + q] - o;
-                dist = dist + df * df;
-                nrm = nrm + o * o;
-            }
+            if ((Ds & 3) == 0) {
+#pragma unroll 4
+                for (int q = 0; q < Ds; q += 4) {
+                    const float4 sv = *reinterpret_cast<const float4 *>(state + r * Ds + q);
+                    const float4 ov = so ? *reinterpret_cast<const float4 *>(so + r * Ds + q) : float4{1.0f, 1.0f, 1.0f, 1.0f};
+                    const float d0 = sv.x - ov.x, d1 = sv.y - ov.y, d2 = sv.z - ov.z, d3 = sv.w - ov.w;
+                    dist = dist + d0 * d0; nrm = nrm + ov.x * ov.x;
+                    dist = dist + d1 * d1; nrm = nrm + ov.y * ov.y;
+                    dist = dist + d2 * d2; nrm = nrm + ov.z * ov.z;
+                    dist = dist + d3 * d3; nrm = nrm + ov.w * ov.w;
+                }
+            } else
+                for (int q = 0; q < Ds; ++q) {
+                    const float o = so ? so[r * Ds + q] : 1.0f;
+                    const float df = state[r * Ds + q] - o;
+                    dist = dist + df * df;
+                    nrm = nrm + o * o;
+                }
             f = __fsqrt_rn(dist) > thr * __fsqrt_rn(nrm);
         }
     }
@@ -505,6 +587,7 @@ __global__ void __launch_bounds__(256) k_state_grad_sum(int sg_blocks, int64_t n
     for (int32_t e = sip[r]; e < sip[r + 1]; ++e) acc = __builtin_fmaf(sw[e], d_inp[(int64_t)sdst[e] * in_s + c_aggs + c], acc);
     d_state[t] = d_inp[r * in_s + c] + acc;
 }
+
 
 __global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
 {
@@ -706,7 +789,15 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
         c.hin[l] = h;
         if ((rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
         const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;          // softmax needs the whole row: separate pass, in place
-        if ((rc = gnn_launch_dense(st, n, width, no, h, width, m->W[l], m->b[l], sm ? GNN_ACT_LINEAR : m->acts[l], c.a[l], no))) return rc;
+        if (n > 0) {
+            constexpr int R = 8;
+            const int ni_pad = (width + 3) & ~3;
+            const size_t lds = dense_lds_bytes(R, ni_pad);
+            if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer input width %d too large", width);
+            hipLaunchKernelGGL((k_dense_fwd<R>), cdiv(n, R), 256, lds, st, n, width, ni_pad, no, dense_cshift(no), h, m->W[l], m->b[l],
+                               sm ? GNN_ACT_LINEAR : m->acts[l], c.a[l]);
+            HIPCHK(hipGetLastError());
+        }
         if (n > 0 && sm) {
             hipLaunchKernelGGL(k_act_fwd, cdiv(n, 256), 256, 0, st, n, no, c.a[l], m->acts[l], c.a[l]);
             HIPCHK(hipGetLastError());
@@ -807,7 +898,8 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         p.H = c.hin[l]; p.DZ = d; p.WT = net.WT[l]; p.a_prev = l > 0 ? c.a[l - 1] : nullptr;
         p.keep = net.rate[l] != 0.0f ? c.keep[l] : nullptr;
         p.part = net.part + net.g_off[2 * l]; p.dprev = dprev;
-        const size_t lds = std::max(sizeof(float) * R * p.n_out_pad, sizeof(float) * 2 * 64 * 17);
+        p.cshift = dense_cshift(ni);
+        const size_t lds = std::max(dense_lds_bytes(R, p.n_out_pad), sizeof(float) * 2 * 64 * 17);
         if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer width %d too large", no);
         hipLaunchKernelGGL((k_layer_bwd<R>), (unsigned)(p.wg_blocks + cdiv(n, R)), 256, lds, st, p);
         if (prev_sm) hipLaunchKernelGGL(k_act_bwd, cdiv(n, 256), 256, 0, st, n, ni, dprev, c.a[l - 1], act_prev);
