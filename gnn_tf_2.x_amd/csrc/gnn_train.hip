@@ -1,13 +1,19 @@
 // One training step on the device: training-mode forward through the unrolled state loop, loss, back-propagation through
-// all executed iterations (reference GNN/GNN_BaseClass.py:231-247 around GNN/GNN.py:180-199, :251-280).  The optimizer
-// step stays on the host (the weights are a few hundred KB): this file returns the loss, the iteration count, the raw
-// gradients and the BatchNormalization batch statistics of every executed body.
+// all executed iterations, optimizer update (reference GNN/GNN_BaseClass.py:231-247 around GNN/GNN.py:180-199, :251-280).
+// The step returns the loss, the iteration count, the raw gradients and the BatchNormalization batch statistics of every
+// executed body; with gnn_loop_arm_optimizer the Adam / SGD update and the moving statistics are applied on the device too
+// (weights, optimizer slots and gradients never leave HBM) and the host waits for the device once per TRAIN_CHUNK bodies
+// of the forward pass and once at the end of the step.
 //
 // Keras training semantics (not in the reference repository; restated in oracle/gnn_train_oracle.py):
 //   Dropout: y = x * mask / (1 - rate), fresh mask per call (negative rate: AlphaDropout);  BatchNormalization: batch mean / biased batch variance;
 //   categorical_crossentropy(from_logits=False): p = out / sum(out), clip to [1e-7, 1 - 1e-7], -sum t log p.
-// This path is built from simple per-op kernels (correctness first; training graphs are small batches); float32 with
-// atomically accumulated weight gradients, so it is compared with the oracle to a tolerance, not bit for bit.
+// Launch structure (the graphs of a training batch are small: the step is bound by the NUMBER of launches, so every body is few,
+// fused kernels): forward body = concat + gather + Dropout + gate (k_train_input), one k_dense_fwd per layer, two
+// BatchNormalization kernels; backward body = two BatchNormalization kernels, one k_layer_bwd per layer (weight / bias gradient
+// tiles beside d h_in, with the Dropout / activation derivative as its epilogue), one k_state_grad_sum.  float32; every
+// reduction over rows leaves per-chunk partials that are added in a fixed order (no float atomics, run-to-run identical), so
+// results are compared with the float64 oracle to a tolerance, not bit for bit.
 #include <math.h>
 #include <string.h>
 
@@ -338,42 +344,57 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_s
 }
 
 // Weight and bias gradient of one Dense layer over one row chunk: part[chunk * pstride + i * n_out + j] = sum_r H'[r, i] DZ[r, j]
-// with H' = [H | 1] (row i = n_in is the bias gradient: dW and db are adjacent in the gradient vector).  16 x 16 outputs per
-// block, 64 rows staged per step.  lds: 2 x 64 x 17 floats.
+// with H' = [H | 1] (row i = n_in is the bias gradient: dW and db are adjacent in the gradient vector).  32 x 32 outputs per
+// block, 2 x 2 per thread (one 8-byte LDS read of each operand per four products), 64 rows staged per step, the next step's
+// rows fetched into registers while this step's products run.  lds: 2 x 64 x 34 floats.
+#define GNN_WG_TILE 32
+#define GNN_WG_LD 34
 __device__ __forceinline__ void wgrad_block(int bx, int by, int bz, int64_t n, int n_in, int n_out, const float *__restrict__ H,
                                             const float *__restrict__ DZ, float *part, int64_t pstride, int64_t rows_per_block, float *lds)
 {
-    float (*sh)[17] = reinterpret_cast<float (*)[17]>(lds);
-    float (*sz)[17] = reinterpret_cast<float (*)[17]>(lds + 64 * 17);
-    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
-    const int i0 = bx * 16, j0 = by * 16;
+    float *sh = lds, *sz = lds + 64 * GNN_WG_LD;
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;            // outputs (i0 + 2 ti + {0, 1}, j0 + 2 tj + {0, 1})
+    const int lr = threadIdx.x >> 5, lc = threadIdx.x & 31;            // loader: rows lr + 8 q, column lc
+    const int i0 = bx * GNN_WG_TILE, j0 = by * GNN_WG_TILE;
     const int64_t r0 = (int64_t)bz * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    float acc = 0.0f;
-    float hv[4], zv[4];
+    float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;
+    float hv[8], zv[8];
     auto fetch = [&](int64_t r) {                  // this thread's share of the 64-row step at r, into registers
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int64_t row = r + ti + 16 * q;
+        for (int q = 0; q < 8; ++q) {
+            const int64_t row = r + lr + 8 * q;
             const bool in = row < r1;
-            hv[q] = !in ? 0.0f : (i0 + tj < n_in ? H[row * n_in + i0 + tj] : (i0 + tj == n_in ? 1.0f : 0.0f));
-            zv[q] = (in && j0 + tj < n_out) ? DZ[row * n_out + j0 + tj] : 0.0f;
+            hv[q] = !in ? 0.0f : (i0 + lc < n_in ? H[row * n_in + i0 + lc] : (i0 + lc == n_in ? 1.0f : 0.0f));
+            zv[q] = (in && j0 + lc < n_out) ? DZ[row * n_out + j0 + lc] : 0.0f;
         }
     };
     if (r0 < r1) fetch(r0);
     for (int64_t r = r0; r < r1; r += 64) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { sh[ti + 16 * q][tj] = hv[q]; sz[ti + 16 * q][tj] = zv[q]; }
+        for (int q = 0; q < 8; ++q) { sh[(lr + 8 * q) * GNN_WG_LD + lc] = hv[q]; sz[(lr + 8 * q) * GNN_WG_LD + lc] = zv[q]; }
         __syncthreads();
         if (r + 64 < r1) fetch(r + 64);            // the next step's loads fly during this step's products
 #pragma unroll 16
-        for (int q = 0; q < 64; ++q) acc = __builtin_fmaf(sh[q][ti], sz[q][tj], acc);
+        for (int q = 0; q < 64; ++q) {
+            const float2 hq = *reinterpret_cast<const float2 *>(sh + q * GNN_WG_LD + 2 * ti);
+            const float2 zq = *reinterpret_cast<const float2 *>(sz + q * GNN_WG_LD + 2 * tj);
+            a00 = __builtin_fmaf(hq.x, zq.x, a00); a01 = __builtin_fmaf(hq.x, zq.y, a01);
+            a10 = __builtin_fmaf(hq.y, zq.x, a10); a11 = __builtin_fmaf(hq.y, zq.y, a11);
+        }
         __syncthreads();
     }
-    if (i0 + ti <= n_in && j0 + tj < n_out) part[(size_t)bz * pstride + (size_t)(i0 + ti) * n_out + j0 + tj] = acc;
+    float *out = part + (size_t)bz * pstride;
+    const int i = i0 + 2 * ti, j = j0 + 2 * tj;
+    if (i <= n_in) {
+        if (j < n_out) out[(size_t)i * n_out + j] = a00;
+        if (j + 1 < n_out) out[(size_t)i * n_out + j + 1] = a01;
+    }
+    if (i + 1 <= n_in) {
+        if (j < n_out) out[(size_t)(i + 1) * n_out + j] = a10;
+        if (j + 1 < n_out) out[(size_t)(i + 1) * n_out + j + 1] = a11;
+    }
 }
 
-// d h_in = d z . W^T, then (fused) the way back through what produced h_in: Dropout (keep != NULL) and the previous layer's
-// activation (act >= 0: d <- d * act'(a_prev)).  R rows of d z staged in LDS, one thread per column of h_in, as k_dense.
 // Dense products of the training step, Y[r, j] = sum_k X[r, k] M[k, j] on R rows per block: 256 threads = CW output columns x KG
 // slices of the k range (CW = 2^cshift >= min(columns, 64)); every thread runs the fmaf chain of its slice (one to a few iterations
 // even for narrow layers: the loop over k is a chain of L2 round trips), the KG partial sums of an output are added in slice order
@@ -515,16 +536,39 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
                 skip = true;
                 if ((cc & 3) == 0) {
                     float4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
-                    for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) {
-                        const float w = adj_w[e];
-                        const float4 x = *reinterpret_cast<const float4 *>(state + (int64_t)adj_src[e] * Ds + cc);
-                        a4.x = __builtin_fmaf(w, x.x, a4.x); a4.y = __builtin_fmaf(w, x.y, a4.y);
-                        a4.z = __builtin_fmaf(w, x.z, a4.z); a4.w = __builtin_fmaf(w, x.w, a4.w);
+                    const int32_t e1 = indptr[r + 1];
+                    for (int32_t e = indptr[r]; e < e1; e += 4) {          // four arcs per step: their loads are in flight together
+                        float w[4];
+                        float4 x[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool in = e + u < e1;
+                            w[u] = in ? adj_w[e + u] : 0.0f;
+                            x[u] = in ? *reinterpret_cast<const float4 *>(state + (int64_t)adj_src[e + u] * Ds + cc) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (e + u < e1) {
+                                a4.x = __builtin_fmaf(w[u], x[u].x, a4.x); a4.y = __builtin_fmaf(w[u], x[u].y, a4.y);
+                                a4.z = __builtin_fmaf(w[u], x[u].z, a4.z); a4.w = __builtin_fmaf(w[u], x[u].w, a4.w);
+                            }
                     }
                     inp[i] = a4.x; inp[i + 1] = a4.y; inp[i + 2] = a4.z; inp[i + 3] = a4.w;
                 }
-            } else
-                for (int32_t e = indptr[r]; e < indptr[r + 1]; ++e) v = __builtin_fmaf(adj_w[e], state[(int64_t)adj_src[e] * Ds + cc], v);
+            } else {
+                const int32_t e1 = indptr[r + 1];
+                for (int32_t e = indptr[r]; e < e1; e += 4) {
+                    float w[4], x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool in = e + u < e1;
+                        w[u] = in ? adj_w[e + u] : 0.0f;
+                        x[u] = in ? state[(int64_t)adj_src[e + u] * Ds + cc] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (e + u < e1) v = __builtin_fmaf(w[u], x[u], v);
+                }
+            }
         } else
             v = tmpl[i];
         if (rate != 0.0f) {
@@ -584,7 +628,18 @@ __global__ void __launch_bounds__(256) k_state_grad_sum(int sg_blocks, int64_t n
     const int64_t r = t / Ds;
     const int c = (int)(t - r * Ds);
     float acc = 0.0f;
-    for (int32_t e = sip[r]; e < sip[r + 1]; ++e) acc = __builtin_fmaf(sw[e], d_inp[(int64_t)sdst[e] * in_s + c_aggs + c], acc);
+    const int32_t e1 = sip[r + 1];
+    for (int32_t e = sip[r]; e < e1; e += 4) {                  // four arcs per step: their loads are in flight together
+        float w[4], x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = e + u < e1;
+            w[u] = in ? sw[e + u] : 0.0f;
+            x[u] = in ? d_inp[(int64_t)sdst[e + u] * in_s + c_aggs + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (e + u < e1) acc = __builtin_fmaf(w[u], x[u], acc);
+    }
     d_state[t] = d_inp[r * in_s + c] + acc;
 }
 
@@ -893,13 +948,13 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         LayerBwd p;
         p.n = n; p.rows_per_block = rpb; p.pstride = ps;
         p.n_in = ni; p.n_out = no; p.n_out_pad = (no + 3) & ~3; p.act = prev_sm ? -1 : act_prev;
-        p.wg_bx = (int)cdiv(ni + 1, 16); p.wg_by = (int)cdiv(no, 16); p.wg_blocks = p.wg_bx * p.wg_by * parts;
+        p.wg_bx = (int)cdiv(ni + 1, GNN_WG_TILE); p.wg_by = (int)cdiv(no, GNN_WG_TILE); p.wg_blocks = p.wg_bx * p.wg_by * parts;
         p.rate = net.rate[l];
         p.H = c.hin[l]; p.DZ = d; p.WT = net.WT[l]; p.a_prev = l > 0 ? c.a[l - 1] : nullptr;
         p.keep = net.rate[l] != 0.0f ? c.keep[l] : nullptr;
         p.part = net.part + net.g_off[2 * l]; p.dprev = dprev;
         p.cshift = dense_cshift(ni);
-        const size_t lds = std::max(dense_lds_bytes(R, p.n_out_pad), sizeof(float) * 2 * 64 * 17);
+        const size_t lds = std::max(dense_lds_bytes(R, p.n_out_pad), sizeof(float) * 2 * 64 * GNN_WG_LD);
         if (lds > 64 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer width %d too large", no);
         hipLaunchKernelGGL((k_layer_bwd<R>), (unsigned)(p.wg_blocks + cdiv(n, R)), 256, lds, st, p);
         if (prev_sm) hipLaunchKernelGGL(k_act_bwd, cdiv(n, 256), 256, 0, st, n, ni, dprev, c.a[l - 1], act_prev);
