@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(PIPE_THREADS, 2) k_pipe(const GnnFusedArgs a)
                 float d2 = 0.0f, o2 = 0.0f;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) { d2 = d2 + fl[L_NORM + (lane * 16 + s) * 2]; o2 = o2 + fl[L_NORM + (lane * 16 + s) * 2 + 1]; }
-                moved = __fsqrt_rn(d2) > a.thr * __fsqrt_rn(o2);
+                moved = sqrtf(d2) > a.thr * sqrtf(o2);
             }
             if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
         }

@@ -903,7 +903,7 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
         const float dd = d * d;
         s_ = s_ + dd;
     }
-    const float root = __fsqrt_rn(s_);
+    const float root = sqrtf(s_);
     const float nrm = shfl_f(root, (lane & 31) + 32);
     const float rhs = a.thr * nrm;
     const int moved = (half == 0) && ((lane & 31) < nvalid) && (root > rhs);
@@ -933,7 +933,7 @@ __device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float 
             s_ = s_ + dd;
         }
     }
-    const float root = __fsqrt_rn(s_);
+    const float root = sqrtf(s_);
     const float nrm = shfl_f(root, (lane & 31) + 32);
     const float rhs = a.thr * nrm;
     const int moved = (half == 0) && (root > rhs);
@@ -974,7 +974,7 @@ __device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, flo
         }
     d2 = d2 + shfl_f(d2, lane ^ 32);
     o2 = o2 + shfl_f(o2, lane ^ 32);
-    const float root = __fsqrt_rn(d2), nrm = __fsqrt_rn(o2);
+    const float root = sqrtf(d2), nrm = sqrtf(o2);
     const int moved = root > a.thr * nrm;
     if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

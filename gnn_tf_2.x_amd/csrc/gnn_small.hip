@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
                 dist = dist + dd;
                 nrm = nrm + 1.0f;
             }
-            moved = __fsqrt_rn(dist) > a0.thr * __fsqrt_rn(nrm);
+            moved = sqrtf(dist) > a0.thr * sqrtf(nrm);
         }
         go = arrive_and_gate(0, __any(moved));
     }

@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
                     dist = dist + df * df;
                     nrm = nrm + o * o;
                 }
-            f = __fsqrt_rn(dist) > thr * __fsqrt_rn(nrm);
+            f = sqrtf(dist) > thr * sqrtf(nrm);
         }
     }
     if (__any(f) && (threadIdx.x & 63) == 0) gnn_flag_raise(flag);
