@@ -397,7 +397,7 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     // output stage inside the launch when it is the usual one-layer head (same condition as k_out1)
     *output_done = false;
     const gnn_mlp *ou = l->ou;
-    if (!l->edge_mode && g->n_masked && ou->n_layers == 1 && l->T <= 8) {
+    if (!l->edge_mode && g->n_masked && ou->n_layers == 1 && l->T <= 8 && l->Ds + l->NLc <= 64 && l->Ds <= 32 && g->NL <= 32) {
         c.out = l->out; c.mask = g->sh->mask; c.mask_pos = g->sh->masked_rows + g->n_masked;
         c.nodes_own = g->nodes + (size_t)g->own_off * g->NL;
         c.ow = ou->W[0]; c.ob = ou->b[0];
@@ -406,10 +406,27 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
         *output_done = true;
     }
     const unsigned grid = (unsigned)((g->n_rows + 31) / 32);
-    const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 96 + 4);
+    const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 160 + 544 + 2048 + 4);    // tile, row pointers, epilogue vectors, head, scratch
     const int rnd = g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
+#ifdef GNN_DIAG
+    static const char *small_stamp_file = getenv("GNN_SMALL_STAMPS");
+    static unsigned long long *small_stamp_buf = nullptr;
+    if (small_stamp_file) {
+        if (!small_stamp_buf) HIPCHK(hipMalloc((void **)&small_stamp_buf, 256 * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(small_stamp_buf, 0, 256 * sizeof(unsigned long long), l->stream));
+        a.stamps = small_stamp_buf;
+    }
+#endif
     if (!gnn_small_launch(p.layers, p.act, p.kk0, rnd, a, c, grid, lds, l->stream))
         return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
     HIPCHK(hipGetLastError());
+#ifdef GNN_DIAG
+    if (small_stamp_file) {
+        unsigned long long host[256];
+        HIPCHK(hipStreamSynchronize(l->stream));
+        HIPCHK(hipMemcpy(host, small_stamp_buf, sizeof(host), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(small_stamp_file, "wb")) { fwrite(host, sizeof(unsigned long long), 256, f); fclose(f); }
+    }
+#endif
     return GNN_OK;      // k and the status word are written straight into the pinned host words
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ void small_layer0(const float *xb, const float (&w)[K
 template <int ACT>
 __device__ __forceinline__ void small_layer(f32x16 &hin, const float *bias_prev, int half, const float (&w)[16], f32x16 &acc)
 {
-    tile_epilogue<ACT, false>(hin, bias_prev, nullptr, nullptr, 0, half);
+    tile_epilogue<ACT, false, false, true>(hin, bias_prev, nullptr, nullptr, 0, half);     // bias_prev: staged in LDS at kernel start
     acc_to_operand(hin);
 #pragma unroll
     for (int ss = 0; ss < 16; ++ss) {
@@ -49,13 +49,47 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
+#ifdef GNN_DIAG      // diagnostic build only: s_memtime of workgroup 0 at every phase boundary (GNN_SMALL_STAMPS=<file>)
+    int stamp_n = 0;
+#define SMALL_STAMP()                                                                                   \
+    do {                                                                                                \
+        if (a0.stamps && blockIdx.x == 0) {                                                             \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                 \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                 \
+            if (lane == 0 && stamp_n < 250) a0.stamps[stamp_n] = t_;                                    \
+            ++stamp_n;                                                                                  \
+        }                                                                                               \
+    } while (0)
+#else
+#define SMALL_STAMP() do { } while (0)
+#endif
+    SMALL_STAMP();
     const int KP = a0.KP, Ds = a0.Ds, c_aggs = a0.c_aggs, half = lane >> 5;
     float *X = lds;
     int *ipt = reinterpret_cast<int *>(lds + 32 * KP + 32);
     float *ep = lds + 32 * KP + 32 + 36;                          // last-layer bias, BatchNormalization scale / shift
+    float *hb = ep + 96;                                          // biases of the hidden layers [2][32]
+    float *hw = ep + 160;                                         // net_output head: W [wf * T <= 512], then b | BN scale | BN shift [3][8]
+    float *scr = hw + 544;                                        // scratch [2048]: the tile's final state rows and label rows
     for (int t = lane; t < 3 * 32; t += 64) {
         const int which = t >> 5, f = t & 31;
         ep[t] = which == 0 ? a0.bias[LAYERS - 1][f] : (a0.bn_scale ? (which == 1 ? a0.bn_scale[f] : a0.bn_shift[f]) : 0.0f);
+    }
+    if constexpr (LAYERS >= 2) {
+        const int t = lane;                                       // 64 lanes = 2 x 32 features
+        if (t < 32 * (LAYERS - 1)) hb[t] = a0.bias[t >> 5][t & 31];
+    }
+    if (c.out) {
+        const int nw = (a0.Ds + c.NLc) * c.T;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (lane + 64 * u < nw) hw[lane + 64 * u] = c.ow[lane + 64 * u];
+        if (lane < 24) {
+            const int which = lane >> 3, q = lane & 7;
+            float v = which == 1 ? 1.0f : 0.0f;
+            if (q < c.T) v = which == 0 ? c.ob[q] : (c.obn_scale ? (which == 1 ? c.obn_scale[q] : c.obn_shift[q]) : v);
+            hw[512 + lane] = v;
+        }
     }
     const int64_t i0 = (int64_t)blockIdx.x * 32;
     const int nvalid = (int)((a0.n_rows - i0) < 32 ? (a0.n_rows - i0) : 32);
@@ -80,6 +114,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     if (blockIdx.x == 0)
         for (int t = lane; t < c.n_words; t += 64) c.zero_words[t] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    SMALL_STAMP();                                                   // 1: set-up loads issued (weights, row pointers)
     const unsigned n_wg = gridDim.x;
     // Grid barrier + gate in ONE word per body: after its write-through stores have drained, every workgroup adds
     // 1 (+ 0x10000 when one of its nodes still moves) to word[b]; the word is complete when its low half reaches the number of
@@ -111,20 +146,29 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     {
         const float *init = c.init + i0 * Ds;
         float *own0 = c.state0 + (a0.row_begin + i0) * Ds;
-        const int total = nvalid * Ds;
-        for (int t = lane; t < total; t += 64) sstore1<true>(own0 + t, gload1(init + t));
+        const int total = nvalid * Ds;                          // <= 32 x 32: sixteen loads per lane at most, all in flight at once
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (lane + 64 * u < total) ? gload1(init + lane + 64 * u) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (lane + 64 * u < total) { sstore1<true>(own0 + lane + 64 * u, v[u]); X[lane + 64 * u] = v[u]; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         int moved = 0;
         if (lane < nvalid) {
             float dist = 0.0f, nrm = 0.0f;
-            for (int f = 0; f < Ds; ++f) {
-                const float df = gload1(init + lane * Ds + f) - 1.0f;
+            for (int f = 0; f < Ds; ++f) {                      // the rows just staged in LDS (the tile itself is built by body 0)
+                const float df = X[lane * Ds + f] - 1.0f;
                 const float dd = df * df;
                 dist = dist + dd;
                 nrm = nrm + 1.0f;
             }
             moved = sqrtf(dist) > a0.thr * sqrtf(nrm);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        SMALL_STAMP();                                               // 2: initial state copied, first condition
         go = arrive_and_gate(0, __any(moved));
+        SMALL_STAMP();                                               // 3: gate 0
     }
     int k = 0;
     for (; k < c.max_iter && go == 1; ++k) {
@@ -134,6 +178,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         a.state_nxt = ((k & 1) ? c.state0 : c.state1) + a0.row_begin * Ds;
         load_tile_generic<true, RND>(a, X, ipt, i0, lane, nvalid, KP, c_aggs, k > 0);     // k > 0: the tile skeleton is still in LDS
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        SMALL_STAMP();                                               // body + 0: tile loaded (gather)
         const float *xb = X + (lane & 31) * KP + half;
         f32x16 out;
         if constexpr (LAYERS == 1) {
@@ -144,12 +189,12 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
             small_layer0<KK0>(xb, w0, h1);
             if constexpr (LAYERS == 2) {
                 out = f32x16{};
-                small_layer<ACT>(h1, a.bias[0], half, w1, out);
+                small_layer<ACT>(h1, hb, half, w1, out);
             } else {
                 f32x16 h2 = {};
-                small_layer<ACT>(h1, a.bias[0], half, w1, h2);
+                small_layer<ACT>(h1, hb, half, w1, h2);
                 out = f32x16{};
-                small_layer<ACT>(h2, a.bias[1], half, w2, out);
+                small_layer<ACT>(h2, hb + 32, half, w2, out);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -164,10 +209,13 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        SMALL_STAMP();                                               // body + 1: dense layers, new state in LDS
         int moved = 0;
         check_store_generic<true>(a, X, i0, lane, nvalid, KP, c_aggs, &moved);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        SMALL_STAMP();                                               // body + 2: condition, row stores drained
         go = arrive_and_gate(k + 1, moved);
+        SMALL_STAMP();                                               // body + 3: barrier + gate
     }
     if (go < 0) {
         if (c.host_result && lane == 0) c.host_result[1] = 1;
@@ -179,49 +227,68 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     }
     // ---- apply_filters + one-layer net_output on the tile's masked rows (GNN.py:275-279), arithmetic as k_out1: k-ordered fmaf
     // chain per output, bias, softmax / activation, BatchNormalization ------------------------------------------------------
-    if (c.out && lane < nvalid && c.mask[i0 + lane]) {
-        const float *sfin = ((k & 1) ? c.state1 : c.state0) + (a0.row_begin + i0 + lane) * Ds;     // this tile's own stores
-        const float *nod = c.nodes_own + (i0 + lane) * c.NL;
-        const int wf = Ds + c.NLc, T = c.T;
-        float y[8];
+    // The tile's final state rows (its own write-through stores) and label rows are contiguous in memory: all lanes copy them into
+    // LDS with every load in flight at once (one round trip, not one per k-step); the head's weights were staged at kernel start.
+    if (c.out) {
+        const int wf = Ds + c.NLc, T = c.T, NL = c.NL, NLc = c.NLc;
+        const float *sfin = ((k & 1) ? c.state1 : c.state0) + (a0.row_begin + i0) * Ds;
+        const float *nod = c.nodes_own + i0 * NL;
+        const int ns = nvalid * Ds, nl = NLc ? nvalid * NL : 0;          // <= 1024 each (Ds, NL <= 32)
+        float sv[16], lv[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = 0.0f;
-        for (int kk = 0; kk < wf; ++kk) {
-            const float x = kk < Ds ? sload1<true>(sfin + kk) : gload1(nod + (kk - Ds));
+        for (int u = 0; u < 16; ++u) {
+            sv[u] = (lane + 64 * u < ns) ? sload1<true>(sfin + lane + 64 * u) : 0.0f;
+            lv[u] = (lane + 64 * u < nl) ? gload1(nod + lane + 64 * u) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (lane + 64 * u < ns) scr[lane + 64 * u] = sv[u];
+            if (lane + 64 * u < nl) scr[1024 + lane + 64 * u] = lv[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool on = lane < nvalid && c.mask[i0 + (lane < nvalid ? lane : 0)];
+        if (on) {
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = 0.0f;
+            for (int kk = 0; kk < wf; ++kk) {                            // k-ordered fmaf chain per output, as k_out1
+                const float x = kk < Ds ? scr[lane * Ds + kk] : scr[1024 + lane * NL + (kk - Ds)];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < T) y[j] = __builtin_fmaf(x, hw[kk * T + j], y[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (j < T) y[j] = __builtin_fmaf(x, gload1(c.ow + kk * T + j), y[j]);
-        }
+                if (j < T) y[j] = y[j] + hw[512 + j];
+            float v[8];
+            if (c.oact == GNN_ACT_SOFTMAX) {
+                float mx = y[0];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < T) y[j] = y[j] + gload1(c.ob + j);
-        float v[8];
-        if (c.oact == GNN_ACT_SOFTMAX) {
-            float mx = y[0];
+                for (int q = 1; q < 8; ++q)
+                    if (q < T) mx = y[q] > mx ? y[q] : mx;
+                float sum = 0.0f;
 #pragma unroll
-            for (int q = 1; q < 8; ++q)
-                if (q < T) mx = y[q] > mx ? y[q] : mx;
-            float sum = 0.0f;
+                for (int q = 0; q < 8; ++q)
+                    if (q < T) { v[q] = gnn_expf(y[q] - mx); sum = sum + v[q]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < T) { v[q] = gnn_expf(y[q] - mx); sum = sum + v[q]; }
+                for (int q = 0; q < 8; ++q)
+                    if (q < T) v[q] = __fdiv_rn(v[q], sum);
+            } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < T) v[q] = __fdiv_rn(v[q], sum);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (q < T) v[q] = gnn_act(y[q], c.oact);
-        }
-        float *o = c.out + (int64_t)c.mask_pos[i0 + lane] * T;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (q < T) {
-                float r = v[q];
-                if (c.obn_scale) { const float t2 = r * gload1(c.obn_scale + q); r = t2 + gload1(c.obn_shift + q); }
-                o[q] = r;
+                for (int q = 0; q < 8; ++q)
+                    if (q < T) v[q] = gnn_act(y[q], c.oact);
             }
+            float *o = c.out + (int64_t)c.mask_pos[i0 + lane] * T;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < T) {
+                    float r = v[q];
+                    if (c.obn_scale) { const float t2 = r * hw[520 + q]; r = t2 + hw[528 + q]; }
+                    o[q] = r;
+                }
+        }
     }
+    SMALL_STAMP();                                                   // last: output stage
 }
 
 template <int LAYERS, int ACT>
