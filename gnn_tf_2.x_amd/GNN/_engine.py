@@ -21,7 +21,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loss_grad',
            'gnn_loop_set_impl', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
-           'gnn_comm_create_loopback', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
+           'gnn_comm_create_loopback', 'gnn_graph_set_full_adjacency', 'gnn_loop_set_slice_exchange', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
 
 _lib = None
 
@@ -231,6 +231,11 @@ class Graph:
 
     def update_labels(self, base: 'Graph', loop: 'Loop', get_state: bool, get_output: bool) -> None:
         _check(lib().gnn_graph_update_labels(self._h, base._h, loop._h, C.c_int(bool(get_state)), C.c_int(bool(get_output))))
+
+    def set_full_adjacency(self, n_global: int, indptr, adj_src, adj_w):
+        """gnn_graph_set_full_adjacency: the whole graph's CSR by destination (global ids) for the feature-sliced exchange."""
+        ip, src, w = np.ascontiguousarray(indptr, np.int32), np.ascontiguousarray(adj_src, np.int32), _f32(adj_w)
+        _check(lib().gnn_graph_set_full_adjacency(self._h, C.c_int64(n_global), _ip(ip), _ip(src), _fp(w)))
 
     @staticmethod
     def update_labels_group(dsts, bases, loops, get_state: bool, get_output: bool) -> None:
@@ -460,6 +465,10 @@ class Loop:
         kk = int(k.value)
         return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
                     bn_batch_state=bns[:kk], bn_batch_output=bno)
+
+    def set_slice_exchange(self, on: bool = True):
+        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows."""
+        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(1 if on else 0)))
 
     def arm_optimizer(self, kind: int, hyper, mean: bool, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
         """gnn_loop_arm_optimizer: the next train_step() also applies the optimizer update on the device."""

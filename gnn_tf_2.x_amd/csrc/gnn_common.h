@@ -124,6 +124,11 @@ struct gnn_graph {
     float *arc_labels_own = nullptr, *arc_labels_orig_own = nullptr;
     int base_AL = 0;
     uint64_t label_version = 1;   // bumped whenever node / arc labels are rewritten (gnn_graph_update_labels)
+    // Adjacency of the WHOLE graph (CSR by destination over all N_global rows, global source ids): operand of the feature-sliced
+    // exchange (gnn_loop_set_slice_exchange), where a rank aggregates its columns of the state for every node
+    int32_t *full_indptr = nullptr, *full_src = nullptr;
+    float *full_w = nullptr;
+    int64_t full_rows = 0;
 };
 
 inline const float *gnn_graph_arc_labels(const gnn_graph *g) { return g->arc_labels_own ? g->arc_labels_own : g->sh->arc_labels; }
@@ -210,6 +215,14 @@ struct gnn_loop {
     hipEvent_t ev_total[2] = {nullptr, nullptr};
     float total_ms = 0.f, avg_iter_ms = 0.f;
     int n_iter_timed = 0;
+    // feature-sliced exchange (gnn_loop_set_slice_exchange): rank q aggregates columns [q Cs, (q + 1) Cs) of the state for ALL nodes
+    bool slice_mode = false;
+    int Cs = 0;                             // Ds / world
+    float *sl_send = nullptr;               // [world][shard_rows, Cs]: column slices of the owned state rows, one block per destination
+    float *sl_state = nullptr;              // [N_pad, Cs]: this rank's column slice of every node's state
+    float *sl_agg = nullptr;                // [N_pad, Cs]: its aggregate
+    float *sl_recv = nullptr;               // [world][shard_rows, Cs]: the aggregate of the owned rows, one block per source rank
+    float *agg_own = nullptr;               // [shard_rows, Ds]: aggregated states of the owned rows (GNN.py:234), input of the body
     void *train_ctx = nullptr;              // gnn_train.hip: what train_forward leaves for train_backward
     void *train_arena = nullptr;            // gnn_train.hip: device scratch slabs kept from step to step
 };

@@ -816,11 +816,32 @@ extern "C" int gnn_graph_dims(const gnn_graph *g, int64_t *n_nodes, int64_t *n_r
     return GNN_OK;
 }
 
+extern "C" int gnn_graph_set_full_adjacency(gnn_graph *g, int64_t n_global, const int32_t *indptr, const int32_t *adj_src, const float *adj_w)
+{
+    ARGCHK(g && indptr && n_global > 0, "bad arguments");
+    ARGCHK(n_global == g->N_global, "the shard belongs to a graph of %lld nodes, not %lld", (long long)g->N_global, (long long)n_global);
+    ARGCHK(!g->halo_world, "a boundary-exchange shard numbers its sources in its own compact space: use a full-replica shard");
+    const int64_t e = indptr[n_global];
+    ARGCHK(indptr[0] == 0 && e >= 0 && (e == 0 || (adj_src && adj_w)), "bad CSR");
+    for (int64_t i = 0; i < n_global; ++i) ARGCHK(indptr[i] <= indptr[i + 1], "indptr must be non-decreasing");
+    for (int64_t q = 0; q < e; ++q) ARGCHK(adj_src[q] >= 0 && adj_src[q] < n_global, "adj_src[%lld] out of range", (long long)q);
+    HIPCHK(hipSetDevice(g->device));
+    (void)hipFree(g->full_indptr); (void)hipFree(g->full_src); (void)hipFree(g->full_w);
+    g->full_indptr = nullptr; g->full_src = nullptr; g->full_w = nullptr;
+    int rc = dev_upload(&g->full_indptr, indptr, (size_t)n_global + 1);
+    if (!rc) rc = dev_upload(&g->full_src, adj_src, (size_t)e);
+    if (!rc) rc = dev_upload(&g->full_w, adj_w, (size_t)e);
+    if (rc) return rc;
+    g->full_rows = n_global;
+    return GNN_OK;
+}
+
 extern "C" int gnn_graph_destroy(gnn_graph *g)
 {
     if (!g) return GNN_OK;
     (void)hipSetDevice(g->device);
     (void)hipFree(g->arc_labels_own); (void)hipFree(g->arc_labels_orig_own); (void)hipFree(g->halo_send);
+    (void)hipFree(g->full_indptr); (void)hipFree(g->full_src); (void)hipFree(g->full_w);
     (void)hipFree(g->nodes);
     graph_release_shared(g->sh);
     delete g;
@@ -985,6 +1006,8 @@ struct Rccl {
     int (*CommDestroy)(void *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -1005,7 +1028,7 @@ static int rccl_load()
     if (!g_rccl.field) return gnn_fail(GNN_ERR_COMM, "librccl lacks %s", name);
     SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllGather, "ncclAllGather") SYM(AllReduce, "ncclAllReduce") SYM(GroupStart, "ncclGroupStart")
-    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+    SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
 #undef SYM
     g_rccl.h = h;
     return GNN_OK;
@@ -1342,6 +1365,117 @@ int gnn_launch_copy_cols(hipStream_t st, int64_t n_rows, int w, const float *src
     return GNN_OK;
 }
 
+// ---- feature-sliced exchange --------------------------------------------------------------------------------------------
+// The aggregation state_agg = Adjacency^T . state (GNN.py:234) is independent per COLUMN of the state.  Instead of handing every
+// rank every row of the state (full or boundary replicas: (P - 1) / P of N Ds floats received per rank and iteration), rank q
+// aggregates columns [q Cs, (q + 1) Cs), Cs = Ds / P, for ALL nodes over the whole graph's adjacency, and two all-to-all steps move
+// column slices in and aggregated slices back: 2 (P - 1) / P of (N / P) Ds floats per rank and iteration, P / 2 times less
+// (56 MB instead of 224 MB at N = 1 M, Ds = 64, P = 8).  The fmaf chain of an aggregated element is the same CSR-ordered chain
+// as in the replicated layouts, so the results are bit-identical.
+__global__ void k_slice_pack(int64_t n_rows, int64_t shard_rows, int Ds, int Cs, const float *__restrict__ own, float *__restrict__ send,
+                             const int *gate, int world)
+{
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= shard_rows * Ds) return;
+    const int64_t r = t / Ds;
+    const int f = (int)(t - r * Ds), q = f / Cs, c = f - q * Cs;
+    send[((size_t)q * shard_rows + r) * Cs + c] = r < n_rows ? own[t] : 0.0f;       // padding rows of a short shard travel as zeros
+}
+
+__global__ void k_slice_unpack(int64_t n_rows, int64_t shard_rows, int Ds, int Cs, const float *__restrict__ recv, float *__restrict__ agg,
+                               const int *gate, int world)
+{
+    if (!gnn_gate_open(gate, world)) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * Ds) return;
+    const int64_t r = t / Ds;
+    const int f = (int)(t - r * Ds), q = f / Cs, c = f - q * Cs;
+    agg[t] = recv[((size_t)q * shard_rows + r) * Cs + c];
+}
+
+// all-to-all of equal blocks: block q of `send` goes to rank q, which stores it as block `rank` of its `recv`
+// (which: 0 = sl_send -> peers' sl_state, 1 = sl_agg -> peers' sl_recv)
+static int slice_alltoall(gnn_loop *l, int which)
+{
+    const size_t block = (size_t)l->shard_rows * l->Cs;
+    float *send = which == 0 ? l->sl_send : l->sl_agg;
+    if (l->comm->grp) {
+        gnn_comm_group *grp = l->comm->grp;
+        for (int p = 0; p < l->world; ++p) {
+            gnn_loop *peer = grp->member[p];
+            if (!peer) return gnn_fail(GNN_ERR_STATE, "loopback rank %d has no loop: create one loop per rank and run them with gnn_loop_run_group", p);
+            if (!peer->slice_mode) return gnn_fail(GNN_ERR_STATE, "rank %d does not use the feature-sliced exchange", p);
+            float *dst = (which == 0 ? peer->sl_state : peer->sl_recv) + (size_t)l->rank * block;
+            HIPCHK(hipMemcpyAsync(dst, send + (size_t)p * block, sizeof(float) * block, hipMemcpyDeviceToDevice, l->stream));
+        }
+        return GNN_OK;
+    }
+    float *recv = which == 0 ? l->sl_state : l->sl_recv;
+    NCCLCHK(g_rccl.GroupStart());
+    for (int p = 0; p < l->world; ++p) {
+        NCCLCHK(g_rccl.Send(send + (size_t)p * block, block, NCCL_FLOAT32, p, l->comm->nccl, l->stream));
+        NCCLCHK(g_rccl.Recv(recv + (size_t)p * block, block, NCCL_FLOAT32, p, l->comm->nccl, l->stream));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return GNN_OK;
+}
+
+// the three steps of the sliced aggregation of body k; between them the other ranks of a loopback group take their turn
+static int slice_step_pack(gnn_loop *l, int k)
+{
+    const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
+    const float *own = l->state[k & 1] + (size_t)l->own_off * l->Ds;
+    hipLaunchKernelGGL(k_slice_pack, cdiv(l->shard_rows * l->Ds, 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs, own, l->sl_send,
+                       gate, l->world);
+    HIPCHK(hipGetLastError());
+    return slice_alltoall(l, 0);
+}
+
+static int slice_step_aggregate(gnn_loop *l, int k)
+{
+    const gnn_graph *g = l->g;
+    const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
+    int rc = gnn_launch_spmm(l->stream, g->full_rows, g->full_indptr, g->full_src, g->full_w, l->sl_state, l->Cs, l->Cs, l->sl_agg, l->Cs, gate, l->world);
+    if (rc) return rc;
+    return slice_alltoall(l, 1);
+}
+
+static int slice_step_unpack(gnn_loop *l, int k)
+{
+    const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
+    if (l->g->n_rows) {
+        hipLaunchKernelGGL(k_slice_unpack, cdiv(l->g->n_rows * l->Ds, 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs, l->sl_recv,
+                           l->agg_own, gate, l->world);
+        HIPCHK(hipGetLastError());
+    }
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_set_slice_exchange(gnn_loop *l, int on)
+{
+    ARGCHK(l, "loop is NULL");
+    if (!on) { l->slice_mode = false; return GNN_OK; }
+    ARGCHK(l->world > 1, "the feature-sliced exchange needs a communicator");
+    ARGCHK(l->Ds % l->world == 0, "state width %d is not a multiple of the world size %d", l->Ds, l->world);
+    ARGCHK(l->g->full_indptr, "call gnn_graph_set_full_adjacency first");
+    ARGCHK(!l->g->halo_world, "not on a boundary-exchange shard");
+    HIPCHK(hipSetDevice(l->device));
+    l->Cs = l->Ds / l->world;
+    if (!l->sl_send) {
+        const size_t slice = (size_t)l->N_pad * l->Cs;           // == world * shard_rows * Cs
+        int rc = dev_alloc(&l->sl_send, slice);
+        if (!rc) rc = dev_alloc(&l->sl_state, slice);
+        if (!rc) rc = dev_alloc(&l->sl_agg, slice);
+        if (!rc) rc = dev_alloc(&l->sl_recv, slice);
+        if (!rc) rc = dev_alloc(&l->agg_own, (size_t)l->shard_rows * l->Ds);
+        if (rc) return rc;
+        HIPCHK(hipMemset(l->sl_agg, 0, sizeof(float) * std::max<size_t>(slice, 1)));      // rows past N_global are never written
+    }
+    l->slice_mode = true;
+    return GNN_OK;
+}
+
 static int unfused_iteration(gnn_loop *l, int k)
 {
     const gnn_graph *g = l->g;
@@ -1353,8 +1487,9 @@ static int unfused_iteration(gnn_loop *l, int k)
     int rc = gnn_launch_copy_cols(l->stream, g->n_rows, l->Ds, own_cur, l->Ds, l->inp, l->in_s, gate, P);
     if (rc) return rc;
     // aggregated_states (GNN.py:234) into columns [Ds + NLc, +Ds)
-    rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
-                         l->inp + l->Ds + l->NLc, l->in_s, gate, P);
+    if (l->slice_mode) rc = gnn_launch_copy_cols(l->stream, g->n_rows, l->Ds, l->agg_own, l->Ds, l->inp + l->Ds + l->NLc, l->in_s, gate, P);
+    else rc = gnn_launch_spmm(l->stream, g->n_rows, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, l->state[cur], l->Ds, l->Ds,
+                              l->inp + l->Ds + l->NLc, l->in_s, gate, P);
     if (rc) return rc;
     // net_state (GNN.py:240)
     rc = launch_mlp(l->stream, l->st, g->n_rows, l->inp, l->in_s, own_nxt, l->Ds, l->tmp[0], l->tmp[1], gate, P);
@@ -1526,15 +1661,21 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
         if (ls[r]->profiling) HIPCHK(hipEventRecord(ls[r]->ev_total[0], ls[r]->stream));
         if (!small && (rc = loop_begin(ls[r], fused[r]))) return rc;
     }
-    for (int r = 0; r < n && !small; ++r) if ((rc = loop_exchange(ls[r], 0, 0))) return rc;
+    // (feature-sliced exchange: no rank ever needs another rank's state rows, only the gates travel)
+    for (int r = 0; r < n && !small; ++r) if ((rc = loop_exchange(ls[r], ls[r]->slice_mode ? -1 : 0, 0))) return rc;
     if (small) {
         ls[0]->kfinal_host[1] = 0;
         if ((rc = gnn_small_run(ls[0], &output_done))) return rc;
     }
     for (int k = 0; k < max_iter && !small; ++k) {
+        if (ls[0]->slice_mode) {
+            for (int r = 0; r < n; ++r) if ((rc = slice_step_pack(ls[r], k))) return rc;
+            for (int r = 0; r < n; ++r) if ((rc = slice_step_aggregate(ls[r], k))) return rc;
+            for (int r = 0; r < n; ++r) if ((rc = slice_step_unpack(ls[r], k))) return rc;
+        }
         for (int r = 0; r < n; ++r) if ((rc = loop_body(ls[r], k, fused[r]))) return rc;
         for (int r = 0; r < n; ++r)
-            if ((rc = loop_exchange(ls[r], (k & 1) ^ 1, (size_t)(k + 1) * ls[r]->world * GNN_FLAG_WORDS))) return rc;
+            if ((rc = loop_exchange(ls[r], ls[r]->slice_mode ? -1 : (k & 1) ^ 1, (size_t)(k + 1) * ls[r]->world * GNN_FLAG_WORDS))) return rc;
         if ((k + 1) % GNN_BODY_CHUNK == 0 && k + 1 < max_iter) {
             bool closed = false, c = false;
             for (int r = 0; r < n; ++r) {
@@ -1812,6 +1953,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
     if (l->gate_host) (void)hipHostFree(l->gate_host);
     (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels);
+    (void)hipFree(l->sl_send); (void)hipFree(l->sl_state); (void)hipFree(l->sl_agg); (void)hipFree(l->sl_recv); (void)hipFree(l->agg_own);
     (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out); (void)hipFree(l->ng_part);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
     delete l;

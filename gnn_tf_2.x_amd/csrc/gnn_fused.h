@@ -43,6 +43,8 @@ struct GnnFusedArgs {
     int tile_base;           // first tile of this launch (tickets count from it)
     int full_tiles;          // 1: state width 64 and n_rows a multiple of 32 - launch the full-tile specialisation of the kernel
     int variant;             // tuning switches (bit 0: raised wave priority during the gather); fixed in the shipped build
+    // feature-sliced exchange: aggregated states of the owned rows [n_rows, Ds], computed outside the kernel (no gather), else nullptr
+    const float *agg_in;
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;
 };

@@ -263,6 +263,7 @@ static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs
     a.flag_out = l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS;
     a.world = P;
     a.stamps = nullptr;
+    a.agg_in = l->slice_mode ? l->agg_own : nullptr;
     a.wstride = 1;
     a.tile_base = 0;
     a.full_tiles = 0;
@@ -325,7 +326,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     };
     bool ok = false;
     const int64_t n_full = g->n_rows / 32;
-    if (l->Ds == 64 && p.NTL == 2 && n_full >= 1) {
+    if (l->Ds == 64 && p.NTL == 2 && n_full >= 1 && !a.agg_in) {      // (given aggregates: the general kernel, which has that path)
         // full tiles through the full-tile specialisation (no generic paths compiled in); a partial last tile through a second,
         // one-tile launch of the general kernel with its own ticket counter
         GnnFusedArgs af = a;

@@ -634,6 +634,13 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
         for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + label_col(rc.c, Ds, NLc, c_aggs)] = gload1(src + t);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (a.agg_in) {        // feature-sliced exchange: the aggregate of the owned rows was computed outside (contiguous rows, no gather)
+        const float *src = a.agg_in + i0 * Ds;
+        const int total = nvalid * Ds;
+        RowCol rc(lane, Ds);
+        for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + c_aggs + rc.c] = gload1(src + t);
+        return;
+    }
     if (Ds <= 32) {
         // narrow rows (small label-sized states): lane = (node, column half); all 32 nodes walk their entries at once, so
         // the latency chain is max-degree long instead of 32 / groups passes long
@@ -1102,7 +1109,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     int *ipt = reinterpret_cast<int *>(lds + (size_t)GNN_FUSED_WAVES * 32 * KP + 32) + wave * 36;
     if (lane <= 32) ipt[lane] = ip_cur;               // requested during the previous tile
     const int ip_next_raw = tile_rowptr_request(a, next_tile, lane);      // row pointers of the NEXT tile: on their way during the gather
-    const bool fast64 = FULL || ((Ds == 64) && (nvalid == 32));     // wave-uniform: the BASELINE shape takes the unguarded paths
+    const bool fast64 = FULL || ((Ds == 64) && (nvalid == 32) && !a.agg_in);     // wave-uniform: the BASELINE shape takes the unguarded paths
     // the gather is a chain of few instructions and long memory waits: with a raised priority its loads are issued ahead of the
     // SIMD partner's dense VALU / MFMA stream instead of behind it
     if (a.variant & 1) __builtin_amdgcn_s_setprio(3);

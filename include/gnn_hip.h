@@ -248,6 +248,15 @@ int gnn_graph_create_halo(int64_t n_nodes_global, int rank, int world, int64_t h
                           int64_t n_arcs, const int32_t *indptr, const int32_t *adj_src_replica, const float *adj_w,
                           const float *arc_w, const float *arc_labels, int dim_arc_label, const float *nodes_replica,
                           int dim_node_label, const uint8_t *mask, int device, gnn_graph **out);
+/* Feature-sliced exchange for node-range shards with full-replica numbering (an alternative to exchanging state ROWS).  The
+ * aggregation tf.sparse.sparse_dense_matmul(adjacency, state) (reference GNN/GNN.py:234) is independent per state column, so rank q
+ * aggregates columns [q Ds / P, (q + 1) Ds / P) for ALL nodes over the whole graph's adjacency, and two all-to-all steps per
+ * iteration move column slices of the owned rows in and aggregated slices back: 2 (P - 1) / P^2 of N Ds floats received per rank
+ * and iteration instead of (P - 1) / P (56 MB instead of 224 MB at N = 1 M, Ds = 64, P = 8).  Bit-identical results.
+ *   gnn_graph_set_full_adjacency  the whole graph's CSR by destination (global ids) beside the shard's own rows
+ *   gnn_loop_set_slice_exchange   on != 0: use it (Ds must be a multiple of the world size); every rank of the job alike */
+int gnn_graph_set_full_adjacency(gnn_graph *g, int64_t n_global, const int32_t *indptr, const int32_t *adj_src, const float *adj_w);
+int gnn_loop_set_slice_exchange(gnn_loop *l, int on);
 /* In-process LOOPBACK group: `world` communicators on ONE device sharing one stream; the exchange steps become
  * device-to-device copies between the members' buffers.  It runs the sharded code path (row offsets, padded replicas,
  * per-rank flag slots, every exchange call site) on a single GPU; used by the parity tests, never for speed.  One loop per

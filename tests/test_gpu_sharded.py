@@ -240,3 +240,56 @@ def test_loopback_group_errors():
     with pytest.raises(ValueError):                      # one loop per rank and group
         e.Loop(graphs[0], e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 4, 5, 0.01, comms[0])
     assert e.Loop.run_group(loops) == corc.loop_node(g, st, ou, 4, 5, 0.01, s0)[0]
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+@pytest.mark.parametrize('n,d,hidden', [(1000, 8, (16,)), (4099, 64, (128, 128)), (333, 16, (7,))])
+def test_feature_sliced_exchange_bit_exact(n, d, hidden, world):
+    """gnn_loop_set_slice_exchange: every rank aggregates ITS columns of the state for all nodes over the whole graph's adjacency
+    (two all-to-all steps per iteration instead of the all-gather of rows).  The fmaf chain of an aggregated element is the
+    same CSR-ordered chain as in the replicated layouts: impl 0 / 1 bit-identical to the C oracle, impl 2 within the tolerance
+    of the unsharded run; n = 333 on 8 ranks: the last ranks own nothing, n = 4099: short last shard, partial tiles."""
+    e = _engine()
+    g, st, ou, s0 = _case(300 + n + world, n, d, hidden=hidden)
+    indptr, adj_src, adj_w, _, _ = _csr_parts(g)
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 30, 0.01, s0)
+
+    def sliced(impl):
+        comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 30, 0.01, s0, world, impl)
+        for gr, lp in zip(graphs, loops):
+            gr.set_full_adjacency(n, indptr, adj_src, adj_w)
+            lp.set_slice_exchange(True)
+        return comms, graphs, loops, ranges
+
+    for impl in (1, 0):
+        comms, graphs, loops, ranges = sliced(impl)
+        k = e.Loop.run_group(loops)
+        state, out = _collect(loops, ranges, None)
+        assert k == kc, (impl, k, kc)
+        assert np.array_equal(state, sc), impl
+        assert out.shape == oc.shape and np.array_equal(out, oc), impl
+        k2 = e.Loop.run_group(loops)
+        assert k2 == kc and np.array_equal(_collect(loops, ranges, None)[0], sc)
+        for lp in loops: lp.close()
+        for c in comms: c.close()
+    comms, graphs, loops, ranges = sliced(2)
+    k = e.Loop.run_group(loops)
+    state, out = _collect(loops, ranges, None)
+    ku, su, ou_ = _unsharded(e, g, st, ou, d, 30, 0.01, s0, 2)
+    assert k == ku == kc
+    tol = 2e-6 * max(1.0, float(np.max(np.abs(sc))))
+    assert np.max(np.abs(state - su)) < tol and np.max(np.abs(out - ou_)) < 2e-6
+
+
+def test_feature_sliced_exchange_argument_errors():
+    e = _engine()
+    g, st, ou, s0 = _case(7, 200, 6)
+    comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, 6, 5, 0.01, s0, 4, 1)
+    with pytest.raises((e.EngineError, ValueError)):
+        loops[0].set_slice_exchange(True)                    # no full adjacency yet
+    indptr, adj_src, adj_w, _, _ = _csr_parts(g)
+    graphs[0].set_full_adjacency(200, indptr, adj_src, adj_w)
+    with pytest.raises((e.EngineError, ValueError)):
+        loops[0].set_slice_exchange(True)                    # 6 columns over 4 ranks
+    with pytest.raises((e.EngineError, ValueError)):
+        graphs[1].set_full_adjacency(199, indptr[:200], adj_src, adj_w)      # another graph's size
