@@ -80,6 +80,22 @@ __device__ __forceinline__ bool gnn_gate_open(const int *gate, int world)
     return any != 0;
 }
 
+// The same for a whole workgroup: the gate words are read once per block (one word per thread, OR through LDS) instead of once per
+// thread - the elementwise kernels of the per-op path and of the exchanges have millions of threads.  Every thread of the block
+// must call it (it contains barriers).
+__device__ __forceinline__ bool gnn_gate_open_block(const int *gate, int world)
+{
+    if (!gate) return true;
+    __shared__ int gate_any;
+    if (threadIdx.x == 0) gate_any = 0;
+    __syncthreads();
+    int any = 0;
+    for (int p = threadIdx.x; p < world * GNN_FLAG_SLOTS; p += blockDim.x) any |= gate[p * GNN_FLAG_STRIDE];
+    if (any) gate_any = 1;
+    __syncthreads();
+    return gate_any != 0;
+}
+
 __device__ __forceinline__ void gnn_flag_raise(int *flag_rank_base)
 {
     int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_spmm(int64_t n_rows, const int32_t *__r
                                               const float *__restrict__ X, int width, int64_t ldx,
                                               float *__restrict__ out, int64_t ldo, int lpr, const int *gate, int world)
 {
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t rows_per_pass = ((int64_t)gridDim.x * blockDim.x) / lpr;
     const int lane = (int)(gtid % lpr);
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) k_dense(int64_t n, int n_in, int n_in_pad
                                                const int *gate, int world)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t i0 = (int64_t)blockIdx.x * R;
     for (int t = threadIdx.x; t < R * n_in_pad; t += blockDim.x) {
         const int r = t / n_in_pad, k = t - r * n_in_pad;
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_dense(int64_t n, int n_in, int n_in_pad
 __global__ void k_softmax_bn(int64_t n, int n_out, float *Y, int64_t ldy, const float *bn_scale, const float *bn_shift,
                              const int *gate, int world)
 {
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float *y = Y + i * ldy;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256) k_check(int64_t n_rows, int d, const floa
 {
     extern __shared__ float chk_sh[];                      // ts [256 * 33] (+ to [256 * 33] iff so)
     float *ts = chk_sh, *to = chk_sh + 256 * 33;
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t r0 = (int64_t)blockIdx.x * 256;
     const int64_t i = r0 + threadIdx.x;
     float dist = 0.0f, nrm = 0.0f;
@@ -1349,7 +1349,7 @@ static int loop_exchange(gnn_loop *l, int b, size_t flag_off)
 __global__ void k_copy_cols(int64_t n_rows, int w, const float *__restrict__ src, int64_t lds_, float *__restrict__ dst, int64_t ldd,
                             const int *gate, int world)
 {
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_rows * w) return;
     const int64_t r = t / w;
@@ -1372,26 +1372,35 @@ int gnn_launch_copy_cols(hipStream_t st, int64_t n_rows, int w, const float *src
 // column slices in and aggregated slices back: 2 (P - 1) / P of (N / P) Ds floats per rank and iteration, P / 2 times less
 // (56 MB instead of 224 MB at N = 1 M, Ds = 64, P = 8).  The fmaf chain of an aggregated element is the same CSR-ordered chain
 // as in the replicated layouts, so the results are bit-identical.
+// VEC = 4 when Cs is a multiple of 4 (16-byte pieces), else 1; one thread per piece
+template <int VEC>
 __global__ void k_slice_pack(int64_t n_rows, int64_t shard_rows, int Ds, int Cs, const float *__restrict__ own, float *__restrict__ send,
                              const int *gate, int world)
 {
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= shard_rows * Ds) return;
-    const int64_t r = t / Ds;
-    const int f = (int)(t - r * Ds), q = f / Cs, c = f - q * Cs;
-    send[((size_t)q * shard_rows + r) * Cs + c] = r < n_rows ? own[t] : 0.0f;       // padding rows of a short shard travel as zeros
+    const int pr = Ds / VEC;                                        // pieces per row
+    if (t >= shard_rows * pr) return;
+    const int64_t r = t / pr;
+    const int f = (int)(t - r * pr) * VEC, q = f / Cs, c = f - q * Cs;
+    float *dst = send + ((size_t)q * shard_rows + r) * Cs + c;
+    if (VEC == 4) *reinterpret_cast<float4 *>(dst) = r < n_rows ? *reinterpret_cast<const float4 *>(own + r * Ds + f) : float4{0.f, 0.f, 0.f, 0.f};
+    else *dst = r < n_rows ? own[r * Ds + f] : 0.0f;               // padding rows of a short shard travel as zeros
 }
 
+template <int VEC>
 __global__ void k_slice_unpack(int64_t n_rows, int64_t shard_rows, int Ds, int Cs, const float *__restrict__ recv, float *__restrict__ agg,
                                const int *gate, int world)
 {
-    if (!gnn_gate_open(gate, world)) return;
+    if (!gnn_gate_open_block(gate, world)) return;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_rows * Ds) return;
-    const int64_t r = t / Ds;
-    const int f = (int)(t - r * Ds), q = f / Cs, c = f - q * Cs;
-    agg[t] = recv[((size_t)q * shard_rows + r) * Cs + c];
+    const int pr = Ds / VEC;
+    if (t >= n_rows * pr) return;
+    const int64_t r = t / pr;
+    const int f = (int)(t - r * pr) * VEC, q = f / Cs, c = f - q * Cs;
+    const float *src = recv + ((size_t)q * shard_rows + r) * Cs + c;
+    if (VEC == 4) *reinterpret_cast<float4 *>(agg + r * Ds + f) = *reinterpret_cast<const float4 *>(src);
+    else agg[r * Ds + f] = *src;
 }
 
 // all-to-all of equal blocks: block q of `send` goes to rank q, which stores it as block `rank` of its `recv`
@@ -1426,8 +1435,12 @@ static int slice_step_pack(gnn_loop *l, int k)
 {
     const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
     const float *own = l->state[k & 1] + (size_t)l->own_off * l->Ds;
-    hipLaunchKernelGGL(k_slice_pack, cdiv(l->shard_rows * l->Ds, 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs, own, l->sl_send,
-                       gate, l->world);
+    if (l->Cs % 4 == 0)
+        hipLaunchKernelGGL((k_slice_pack<4>), cdiv(l->shard_rows * (l->Ds / 4), 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs, own,
+                           l->sl_send, gate, l->world);
+    else
+        hipLaunchKernelGGL((k_slice_pack<1>), cdiv(l->shard_rows * l->Ds, 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs, own,
+                           l->sl_send, gate, l->world);
     HIPCHK(hipGetLastError());
     return slice_alltoall(l, 0);
 }
@@ -1445,8 +1458,12 @@ static int slice_step_unpack(gnn_loop *l, int k)
 {
     const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
     if (l->g->n_rows) {
-        hipLaunchKernelGGL(k_slice_unpack, cdiv(l->g->n_rows * l->Ds, 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs, l->sl_recv,
-                           l->agg_own, gate, l->world);
+        if (l->Cs % 4 == 0)
+            hipLaunchKernelGGL((k_slice_unpack<4>), cdiv(l->g->n_rows * (l->Ds / 4), 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs,
+                               l->sl_recv, l->agg_own, gate, l->world);
+        else
+            hipLaunchKernelGGL((k_slice_unpack<1>), cdiv(l->g->n_rows * l->Ds, 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs,
+                               l->sl_recv, l->agg_own, gate, l->world);
         HIPCHK(hipGetLastError());
     }
     return GNN_OK;

@@ -41,7 +41,7 @@ struct GnnFusedArgs {
     const int *Ws_base;
     int ws_bytes, ws_off[GNN_FUSED_MAXL];
     int tile_base;           // first tile of this launch (tickets count from it)
-    int full_tiles;          // 1: state width 64 and n_rows a multiple of 32 - launch the full-tile specialisation of the kernel
+    int full_tiles;          // 1: state width 64 - launch the full-tile specialisation of the kernel (a partial last tile takes its masked branch)
     int variant;             // tuning switches (bit 0: raised wave priority during the gather); fixed in the shipped build
     // feature-sliced exchange: aggregated states of the owned rows [n_rows, Ds], computed outside the kernel (no gather), else nullptr
     const float *agg_in;

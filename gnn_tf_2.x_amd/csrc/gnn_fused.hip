@@ -204,7 +204,10 @@ int gnn_fused_prepare(gnn_loop *l)
     const gnn_graph *g = l->g;
     const int IW = 2 * l->NLc + g->AL;
     if (!l->inv) {
-        HIPCHK(hipMalloc((void **)&l->inv, std::max<size_t>(1, (size_t)g->n_rows * IW) * sizeof(float)));
+        // (rows padded to whole 32-node tiles and zeroed: the full-tile kernel reads the label columns of a partial last tile unguarded)
+        const size_t inv_floats = std::max<size_t>(1, (size_t)((g->n_rows + 31) / 32 * 32) * IW);
+        HIPCHK(hipMalloc((void **)&l->inv, inv_floats * sizeof(float)));
+        HIPCHK(hipMemsetAsync(l->inv, 0, inv_floats * sizeof(float), l->stream));
     }
     if (IW == 0) return GNN_OK;
     // [nodes | Adjacency^T . nodes | ArcNode^T . arc labels]  (GNN.py:263, :259): loop-invariant, and unchanged from run to run
@@ -325,18 +328,13 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         return gnn_fused_launch_l3(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
     };
     bool ok = false;
-    const int64_t n_full = g->n_rows / 32;
-    if (l->Ds == 64 && p.NTL == 2 && n_full >= 1 && !a.agg_in) {      // (given aggregates: the general kernel, which has that path)
-        // full tiles through the full-tile specialisation (no generic paths compiled in); a partial last tile through a second,
-        // one-tile launch of the general kernel with its own ticket counter
+    const int64_t n_tiles64 = (g->n_rows + 31) / 32;
+    if (l->Ds == 64 && p.NTL == 2 && n_tiles64 >= 1 && !a.agg_in) {      // (given aggregates: the general kernel, which has that path)
+        // the full-tile specialisation (no generic paths compiled in) on every tile; a partial last tile takes a wave-uniform
+        // branch with masked row stores / condition votes (the row buffers are padded to whole tiles, rows past n_rows have no arcs)
         GnnFusedArgs af = a;
-        af.full_tiles = 1; af.n_rows = n_full * 32; af.tile_base = 0;
-        ok = go(af, (unsigned)std::min<size_t>((size_t)n_cu, (size_t)n_full));
-        if (ok && g->n_rows % 32) {
-            GnnFusedArgs ar = a;
-            ar.tile_base = (int)n_full; ar.tile_ctr = l->tile_ctr + (l->max_iter + 1) + k; ar.stagger = 0;
-            ok = go(ar, 1);
-        }
+        af.full_tiles = 1; af.tile_base = 0;
+        ok = go(af, (unsigned)std::min<size_t>((size_t)n_cu, (size_t)n_tiles64));
     } else
         ok = go(a, grid);
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);

@@ -994,6 +994,68 @@ __device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, flo
     for (int u = 0; u < 8; ++u) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = v[u];
 }
 
+// The same two for the LAST tile of a range whose row count is not a multiple of 32 (wave-uniform branch in the full-tile kernel: a
+// second, one-tile launch of the general kernel for that tile cost 70 - 100 us per iteration).  Rows >= nvalid of the tile exist
+// in memory (the buffers are padded to whole tiles) and have no arcs; what they compute stays in LDS: their lanes do not vote in
+// condition() and their rows are not stored.
+__device__ __forceinline__ void check_store_fast64_partial(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int KP, int c_aggs, int nvalid)
+{
+    constexpr int Ds = 64;
+    const int half = lane >> 5;
+    const float *xo = X + (lane & 31) * KP, *xn = xo + c_aggs;
+    float s_ = 0.0f;
+#pragma unroll
+    for (int f = 0; f < Ds; f += 16) {
+        float o[16], nw[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { o[u] = xo[f + u]; nw[u] = xn[f + u]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float d = half ? o[u] : (nw[u] - o[u]);
+            const float dd = d * d;
+            s_ = s_ + dd;
+        }
+    }
+    const float root = sqrtf(s_);
+    const float nrm = shfl_f(root, (lane & 31) + 32);
+    const float rhs = a.thr * nrm;
+    const int moved = (half == 0) && (lane < nvalid) && (root > rhs);
+    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    float *dst = a.state_nxt + i0 * Ds + lane;
+    const float *xs = X + c_aggs + lane;                                     // row i, feature lane
+    for (int i = 0; i < nvalid; ++i) gptr_w(dst)[i * Ds] = xs[i * KP];
+}
+
+__device__ __forceinline__ void finish_fast64_partial(const GnnFusedArgs &a, float *X, f32x16 (&out)[2], int64_t i0, int lane, int KP, int c_aggs,
+                                                      int nvalid)
+{
+    const int half = lane >> 5;
+    float *xrow = X + (lane & 31) * KP;
+    float d2 = 0.0f, o2 = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * jt + 8 * q + 4 * half;
+            const v4f o = *reinterpret_cast<const v4f *>(xrow + f0);
+            const v4f nw = {out[jt][4 * q], out[jt][4 * q + 1], out[jt][4 * q + 2], out[jt][4 * q + 3]};
+            *reinterpret_cast<v4f *>(xrow + c_aggs + f0) = nw;
+            const v4f d = nw - o;
+            d2 = __builtin_fmaf(d.x, d.x, d2); d2 = __builtin_fmaf(d.y, d.y, d2); d2 = __builtin_fmaf(d.z, d.z, d2); d2 = __builtin_fmaf(d.w, d.w, d2);
+            o2 = __builtin_fmaf(o.x, o.x, o2); o2 = __builtin_fmaf(o.y, o.y, o2); o2 = __builtin_fmaf(o.z, o.z, o2); o2 = __builtin_fmaf(o.w, o.w, o2);
+        }
+    d2 = d2 + shfl_f(d2, lane ^ 32);
+    o2 = o2 + shfl_f(o2, lane ^ 32);
+    const float root = sqrtf(d2), nrm = sqrtf(o2);
+    const int moved = ((lane & 31) < nvalid) && (root > a.thr * nrm);
+    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float *dst = a.state_nxt + i0 * 64 + lane * 4;                           // flat element 256 u + 4 lane = row 4u + lane/16
+    const float *xs = X + (lane >> 4) * KP + c_aggs + (lane & 15) * 4;
+    for (int u = 0; u < 8; ++u)
+        if (4 * u + (lane >> 4) < nvalid) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = *reinterpret_cast<const v4f *>(xs + 4 * u * KP);
+}
+
 // ---- cross-tile prefetch of the dependent loads that open a tile: ticket -> row pointers -> ids of the first gather batch ----
 // Each of them is a full memory round trip in front of the first neighbour row; requested one tile ahead they cost three VGPRs.
 __device__ __forceinline__ int tile_rowptr_request(const GnnFusedArgs &a, int tile, int lane)
@@ -1190,7 +1252,8 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
                 else tile_epilogue<ACT, false, true, true, true>(out[jt], ep, nullptr, nullptr, jt, half);
             }
             GNN_STAMP(6);
-            finish_fast64_aligned(a, X, out, i0, lane, KP, c_aggs);
+            if (nvalid == 32) finish_fast64_aligned(a, X, out, i0, lane, KP, c_aggs);
+            else finish_fast64_partial(a, X, out, i0, lane, KP, c_aggs, nvalid);       // (full-tile kernel on the range's last, partial tile)
             finished = true;
         }
     }
@@ -1208,8 +1271,10 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         GNN_STAMP(6);
-        if constexpr (FULL) check_store_fast64(a, X, i0, lane, KP, c_aggs);
-        else {
+        if constexpr (FULL) {
+            if (nvalid == 32) check_store_fast64(a, X, i0, lane, KP, c_aggs);
+            else check_store_fast64_partial(a, X, i0, lane, KP, c_aggs, nvalid);
+        } else {
             if (fast64) check_store_fast64(a, X, i0, lane, KP, c_aggs);
             else check_store_generic(a, X, i0, lane, nvalid, KP, c_aggs);
         }
@@ -1237,7 +1302,7 @@ inline void launch_one(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, h
     hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
 }
 
-// a.full_tiles: the host asks for the full-tile specialisation (state width 64, a.n_rows a multiple of 32); it exists for NTL == 2
+// a.full_tiles: the host asks for the full-tile specialisation (state width 64); it exists for NTL == 2
 template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
 inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
