@@ -149,13 +149,13 @@ class GNNnodeBased(BaseClass):
         BatchNormalization on batch statistics (the moving statistics are updated as Keras does on every training-mode call).
         The loop then holds the training-mode state / outputs."""
         self._train_calls = getattr(self, '_train_calls', 0) + 1
+        # gamma / beta are read from the device copies (bn_state = None) and the moving statistics are updated there as well
         k, _ = loop.train_forward(self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device), None,
                                   dropout_state=self.net_state.dropout_rates(), dropout_output=self.net_output.dropout_rates(),
-                                  seed=self.seed * 1000003 + self._train_calls, bn_state=self.net_state.bn_gamma_beta(),
-                                  bn_output=self.net_output.bn_gamma_beta())
-        res = loop.train_backward(np.zeros((loop.n_masked, loop.T), np.float32))      # releases the context; yields the batch statistics
-        self.net_state.update_moving_statistics(res['bn_batch_state'])
-        if loop.n_masked: self.net_output.update_moving_statistics(res['bn_batch_output'])
+                                  seed=self.seed * 1000003 + self._train_calls, bn_state=None, bn_output=None)
+        loop.update_moving_statistics(getattr(self.net_state.layers[-1], 'momentum', 0.99), getattr(self.net_output.layers[-1], 'momentum', 0.99))
+        if self.net_state.batch_normalization: self.net_state.mark_device_newer()
+        if self.net_output.batch_normalization: self.net_output.mark_device_newer()
         return k
 
     # ---- training -------------------------------------------------------------------------------------------------------

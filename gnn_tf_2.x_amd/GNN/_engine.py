@@ -18,7 +18,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_graph_derive', 'gnn_graph_derive_edge', 'gnn_graph_set_arc_order', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
-           'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loss_grad',
+           'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loop_update_moving_statistics', 'gnn_loss_grad',
            'gnn_loop_set_impl', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
            'gnn_comm_create_loopback', 'gnn_graph_set_full_adjacency', 'gnn_loop_set_slice_exchange', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
@@ -469,6 +469,10 @@ class Loop:
     def set_slice_exchange(self, on: bool = True):
         """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows."""
         _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(1 if on else 0)))
+
+    def update_moving_statistics(self, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
+        """gnn_loop_update_moving_statistics: the moving statistics of both nets from the last train_forward, on the device."""
+        _check(lib().gnn_loop_update_moving_statistics(self._h, C.c_float(bn_momentum_state), C.c_float(bn_momentum_output)))
 
     def arm_optimizer(self, kind: int, hyper, mean: bool, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
         """gnn_loop_arm_optimizer: the next train_step() also applies the optimizer update on the device."""

@@ -1582,6 +1582,29 @@ extern "C" int gnn_loop_optimizer_step(gnn_loop *l, int kind, const float *hyper
     return rc;
 }
 
+extern "C" int gnn_loop_update_moving_statistics(gnn_loop *l, float bn_momentum_state, float bn_momentum_output)
+{
+    ARGCHK(l, "loop is NULL");
+    TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
+    if (!cx || cx->applied) return gnn_fail(GNN_ERR_STATE, "no training-mode forward pass to take the batch statistics from");
+    HIPCHK(hipSetDevice(l->device));
+    hipStream_t st = l->stream;
+    struct { gnn_mlp *m; Net *net; int calls; float mom; } nets[2] = {{l->st, &cx->ns, cx->k, bn_momentum_state}, {l->ou, &cx->no_, cx->M > 0 ? 1 : 0, bn_momentum_output}};
+    for (auto &n : nets) {
+        if (!n.m->has_bn || n.calls <= 0) continue;
+        const int F = n.m->dims.back();
+        hipLaunchKernelGGL(k_bn_moving, cdiv(F, 64), 64, 0, st, F, n.calls, n.net->stats_all, n.mom, n.m->bn_raw);
+        HIPCHK(hipGetLastError());
+        int rc = gnn_mlp_refresh_bn(n.m, st);
+        if (rc) return rc;
+        n.m->version++;
+        n.m->pack_dirty = true;
+    }
+    cx->applied = true;                           // once per forward pass
+    HIPCHK(hipStreamSynchronize(st));
+    return GNN_OK;
+}
+
 extern "C" int gnn_loop_arm_optimizer(gnn_loop *l, int kind, const float *hyper, int mean, float bn_momentum_state, float bn_momentum_output)
 {
     ARGCHK(l && hyper && (kind == 0 || kind == 1), "bad arguments (kind: 0 SGD, 1 Adam)");

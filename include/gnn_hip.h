@@ -193,6 +193,10 @@ int gnn_loop_train_backward(gnn_loop *l, const float *d_out_nodes, const float *
  *                            state_grad_scale multiplies the net_state gradients.
  * With bn_state / bn_output NULL in the train calls, gamma / beta are the gnn_mlp's own device copy (the one updated here).
  * gnn_mlp_get_weights (above) reads the current arrays back. */
+/* Keras BatchNormalization in training mode also updates its moving statistics when no gradient is taken (a Loop(training=True)
+ * call, reference GNN/GNN.py:251-280 with training=True): moving <- moving * momentum + batch * (1 - momentum) per call, from the
+ * batch statistics of the last gnn_loop_train_forward, on the device.  Once per forward pass; not after an optimizer step. */
+int gnn_loop_update_moving_statistics(gnn_loop *l, float bn_momentum_state, float bn_momentum_output);
 int gnn_loop_arm_optimizer(gnn_loop *l, int kind, const float *hyper, int mean, float bn_momentum_state, float bn_momentum_output);
 int gnn_loop_optimizer_step(gnn_loop *l, int kind, const float *hyper, float state_grad_scale, float bn_momentum_state,
                             float bn_momentum_output);
