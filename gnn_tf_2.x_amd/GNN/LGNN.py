@@ -253,8 +253,7 @@ class LGNN(BaseClass):
             k, out_nodes = loop.train_forward(gnn.net_state.device_mlp(gnn.device), gnn.net_output.device_mlp(gnn.device), None,
                                               dropout_state=gnn.net_state.dropout_rates(), dropout_output=gnn.net_output.dropout_rates(),
                                               masks_state=masks_state[idx], masks_output=masks_output[idx],
-                                              seed=gnn.seed * 1000003 + gnn._train_calls, bn_state=gnn.net_state.bn_gamma_beta(),
-                                              bn_output=gnn.net_output.bn_gamma_beta())
+                                              seed=gnn.seed * 1000003 + gnn._train_calls, bn_state=None, bn_output=None)     # gamma / beta: the device copies
             loops.append(loop); K.append(k)
             outs.append(loop.readout(*g.nodegraph_csr()) if graph_based else out_nodes)
             if idx < L - 1:
@@ -299,6 +298,17 @@ class LGNN(BaseClass):
                     d_out_extra = res['d_arcs'][mask, ALb:ALb + prev.T] if edge_based else res['d_nodes'][mask, c:c + prev.T]
         # ---- update: net_state gradients / k when mean (GNN_BaseClass.py:241); one optimizer over all layers (:244-247) ----
         from GNN import regularizers
+        # Device-side update (gnn_loop_optimizer_step per layer: gradients, weights and optimizer slots stay in HBM) when nothing of
+        # it lives on the host: an optimizer that knows the engine's update rules and no kernel / bias regularizers
+        if (getattr(self, 'device_optimizer', True) and hasattr(self.optimizer, 'device_step_args')
+                and not regularizers.any_regularizer(self.get_dense_layers())):
+            kind_o, hyper = self.optimizer.device_step_args()           # one optimizer step over all layers (reference :244-247)
+            for gnn, loop, k in zip(self.gnns, loops, K):
+                loop.optimizer_step(kind_o, hyper, (1.0 / k) if (mean and k) else 1.0, getattr(gnn.net_state.layers[-1], 'momentum', 0.99),
+                                    getattr(gnn.net_output.layers[-1], 'momentum', 0.99))
+                gnn.net_state.mark_device_newer()
+                gnn.net_output.mark_device_newer()
+            return dict(loss=loss, k=K, grads_state=[r['grads_state'] for r in results], grads_output=[r['grads_output'] for r in results], outs=outs)
         for gnn, r in zip(self.gnns, results):     # regularizer terms of the taped loss (reference GNN_BaseClass.py:223-235)
             for net, key in ((gnn.net_state, 'grads_state'), (gnn.net_output, 'grads_output')):
                 pen, rg = regularizers.penalty_and_gradients(net.dense_layers)

@@ -557,3 +557,44 @@ def test_device_optimizer_matches_host_optimizer(opt_name, graph_based):
     dev.net_state.set_weights(dev.net_state.get_weights())
     k1, _, out1 = dev.Loop(batch)
     assert k0 == k1 and np.array_equal(out0, out1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['parallel', 'residual'])
+def test_lgnn_device_optimizer_matches_host_optimizer(mode):
+    """The joint LGNN step with gnn_loop_optimizer_step per layer (one optimizer step over all layers, reference
+    GNN_BaseClass.py:244-247) against the NumPy optimizer on the same gradients: same weights after two steps."""
+    from GNN import losses, optimizers
+    from GNN.GNN import GNNnodeBased
+    from GNN.LGNN import LGNN
+    from GNN.MLP import MLP, set_seed
+    from GNN.graph_class import GraphObject
+    rng = np.random.default_rng(2)
+    n = 90
+    nodes = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+    g = GraphObject(arcs=random_arcs(rng, n, 270, 1), nodes=nodes, targets=np.eye(2)[rng.integers(0, 2, n)])
+
+    def build(device_optimizer):
+        set_seed(4)
+
+        def model(layer):
+            w = 3 + 2 * (layer > 0)
+            st = MLP(1 + 2 * w, [8, w], 'tanh', 'glorot_normal', 'zeros')                 # BatchNormalization on
+            ou = MLP(w, [2], 'softmax', 'glorot_normal', 'zeros', batch_normalization=False)
+            return GNNnodeBased(net_state=st, net_output=ou, optimizer=None, loss_function=losses.categorical_crossentropy, loss_arguments=None,
+                                state_vect_dim=0, max_iteration=3, threshold=0.01, addressed_problem='c')
+
+        lg = LGNN([model(0), model(1)], False, True, optimizers.Adam(0.01), losses.categorical_crossentropy, None, 'c')
+        lg.device_optimizer = device_optimizer
+        lg.training_mode = mode
+        return lg
+
+    host, dev = build(False), build(True)
+    for _ in range(2):
+        rh, rd = host.training_step(g, True), dev.training_step(g, True)
+        assert rh['k'] == rd['k'] and abs(rh['loss'] - rd['loss']) <= 1e-4 * max(1.0, abs(rh['loss']))
+    for gh, gd in zip(host.gnns, dev.gnns):
+        assert gd.net_state._host_stale
+        for net_h, net_d in ((gh.net_state, gd.net_state), (gh.net_output, gd.net_output)):
+            for a, b in zip(net_h.get_weights(), net_d.get_weights()):
+                assert np.max(np.abs(a - b)) <= 5e-5 * max(1.0, np.max(np.abs(a)))
