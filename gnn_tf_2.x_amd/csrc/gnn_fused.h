@@ -45,6 +45,7 @@ struct GnnFusedArgs {
     int variant;             // tuning switches (bit 0: raised wave priority during the gather); fixed in the shipped build
     // feature-sliced exchange: aggregated states of the owned rows [n_rows, Ds], computed outside the kernel (no gather), else nullptr
     const float *agg_in;
+    int threads;             // threads per workgroup of the launch (0: GNN_FUSED_THREADS)
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;
 };

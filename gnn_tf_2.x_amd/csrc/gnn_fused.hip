@@ -267,6 +267,7 @@ static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs
     a.world = P;
     a.stamps = nullptr;
     a.agg_in = l->slice_mode ? l->agg_own : nullptr;
+    a.threads = 0;
     a.wstride = 1;
     a.tile_base = 0;
     a.full_tiles = 0;
@@ -329,7 +330,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     };
     bool ok = false;
     const int64_t n_tiles64 = (g->n_rows + 31) / 32;
-    if (l->Ds == 64 && p.NTL == 2 && n_tiles64 >= 1 && !a.agg_in) {      // (given aggregates: the general kernel, which has that path)
+    if (l->Ds == 64 && p.NTL == 2 && n_tiles64 >= 1) {
         // the full-tile specialisation (no generic paths compiled in) on every tile; a partial last tile takes a wave-uniform
         // branch with masked row stores / condition votes (the row buffers are padded to whole tiles, rows past n_rows have no arcs)
         GnnFusedArgs af = a;

@@ -894,6 +894,54 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
         }
 }
 
+// Ds == 64, full tile, aggregate GIVEN (a.agg_in: rows of the aggregated state computed by another kernel): three coalesced row
+// copies - own state, aggregate, label columns - instead of the gather.
+template <bool AL16>
+__device__ __forceinline__ void load_tile_given64(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int KP, int c_aggs)
+{
+    constexpr int Ds = 64;
+    v4f own[8], agg[8];
+    {
+        const float *src = a.state_cur + (a.row_begin + i0) * Ds + lane * 4;
+        const float *sag = a.agg_in + i0 * Ds + lane * 4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            own[u] = gload4(src + u * 256);
+            agg[u] = gload4(sag + u * 256);
+        }
+    }
+    float lab[4];
+    const int IW = a.IW, nlab = 32 * IW;
+    {
+        const float *src = a.inv + i0 * IW;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lab[u] = (lane + 64 * u < nlab) ? gload1(src + lane + 64 * u) : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float *x = X + (4 * u + (lane >> 4)) * KP + (lane & 15) * 4;         // flat element 256 u + 4 lane = row 4u + lane/16
+        if constexpr (AL16) { *reinterpret_cast<v4f *>(x) = own[u]; *reinterpret_cast<v4f *>(x + c_aggs) = agg[u]; }
+        else {
+            x[0] = own[u].x; x[1] = own[u].y; x[2] = own[u].z; x[3] = own[u].w;
+            x[c_aggs] = agg[u].x; x[c_aggs + 1] = agg[u].y; x[c_aggs + 2] = agg[u].z; x[c_aggs + 3] = agg[u].w;
+        }
+    }
+    const float inv_iw = 1.0f / (float)(IW > 0 ? IW : 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = lane + 64 * u;
+        if (t < nlab) {
+            const int i = (int)(((float)t + 0.5f) * inv_iw), c = t - i * IW;
+            X[i * KP + label_col(c, Ds, a.NLc, c_aggs)] = lab[u];
+        }
+    }
+    if (nlab > 256)
+        for (int t = 256 + lane; t < nlab; t += 64) {
+            const int i = t / IW, c = t - i * IW;
+            X[i * KP + label_col(c, Ds, a.NLc, c_aggs)] = gload1(a.inv + i0 * IW + t);
+        }
+}
+
 // condition() for the next body + coalesced store of the new rows.  New state sits in columns [c_aggs, c_aggs + Ds).
 // lanes 0..31 sum (new - old)^2, lanes 32..63 sum old^2, ascending feature order, unfused (oracle order).
 // moved_out != nullptr: the verdict "some node of the tile still moves" is returned there instead of raised in a.flag_out
@@ -1092,9 +1140,11 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[N])
         for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
 }
 
-// FULL: state width 64 and only full 32-node tiles (the host sends a partial last tile to a second, one-tile launch of the general
-// kernel): the guarded generic paths are not compiled in at all, which frees registers and scalar registers for the tuned ones.
-template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT, bool FULL = false>
+// FULL: state width 64, the tuned 32-node tile paths only (a partial last tile takes their masked branch): the guarded generic paths
+// are not compiled in at all, which frees registers and scalar registers for the tuned ones.
+// GIVEN (with FULL): the aggregated states come from a.agg_in (feature-sliced exchange) - row copies instead of the gather.  A
+// template parameter, not a branch: a wave-uniform branch in the tile loop of the full-tile kernel cost 3 % (0.700 -> 0.721 ms).
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT, bool FULL = false, bool GIVEN = false>
 __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedArgs a0)
 {
     const GnnFusedArgs &a = a0;      // (shadowed inside the tile loop)
@@ -1110,13 +1160,13 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     const int c_aggs = a.c_aggs;                      // column of the aggregated state block (Ds + NLc + alignment hole)
     // last-layer bias and BatchNormalization scale / shift: staged once per workgroup behind the row-pointer slots
     float *ep = lds + (size_t)GNN_FUSED_WAVES * 32 * KP + 32 + GNN_FUSED_WAVES * 36;
-    for (int t = threadIdx.x; t < 3 * 32 * NTL; t += GNN_FUSED_THREADS) {
+    for (int t = threadIdx.x; t < 3 * 32 * NTL; t += blockDim.x) {
         const int which = t / (32 * NTL), f = t - which * 32 * NTL;
         ep[t] = which == 0 ? a.bias[LAYERS - 1][f] : (a.bn_scale ? (which == 1 ? a.bn_scale[f] : a.bn_shift[f]) : 0.0f);
     }
     float *hb = ep + 3 * 32 * NTL;                    // hidden-layer biases (split path): [LAYERS - 1][32 NT]
     if constexpr (SPLIT && LAYERS > 1)
-        for (int t = threadIdx.x; t < (LAYERS - 1) * 32 * NT; t += GNN_FUSED_THREADS)
+        for (int t = threadIdx.x; t < (LAYERS - 1) * 32 * NT; t += blockDim.x)
             hb[t] = a.bias[t / (32 * NT)][t % (32 * NT)] * (ACT == GNN_ACT_SELU ? 1.44269504088896341f : 1.0f);      // folded SELU: see GNN_S1_E
     __syncthreads();
     // Start-up spread.  All waves of the chip run the same phases on tiles of similar cost: started together they gather together
@@ -1175,7 +1225,8 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // the gather is a chain of few instructions and long memory waits: with a raised priority its loads are issued ahead of the
     // SIMD partner's dense VALU / MFMA stream instead of behind it
     if (a.variant & 1) __builtin_amdgcn_s_setprio(3);
-    if constexpr (FULL) load_tile_fast64<SPLIT, true, GNN_FUSED_DEEP_GATHER>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
+    if constexpr (FULL && GIVEN) load_tile_given64<SPLIT>(a, X, i0, lane, KP, c_aggs);      // feature-sliced exchange: no gather (a.agg_in)
+    else if constexpr (FULL) load_tile_fast64<SPLIT, true, GNN_FUSED_DEEP_GATHER>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
     else {
         if (fast64) load_tile_fast64<SPLIT>(a, X, ipt, i0, lane, KP, c_aggs, src_cur, w_cur);
         else load_tile_generic(a, X, ipt, i0, lane, nvalid, KP, c_aggs);
@@ -1288,18 +1339,18 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
   }
 }
 
-template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT, bool FULL>
+template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT, bool FULL, bool GIVEN = false>
 inline void launch_one(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
     static bool raised[64] = {false};   // dynamic LDS above 64 KiB has to be requested once per kernel AND device
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !raised[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL, GIVEN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (dev >= 0 && dev < 64) raised[dev] = true;
     }
-    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL>), grid, GNN_FUSED_THREADS, lds_bytes, st, a);
+    hipLaunchKernelGGL((k_fused<LAYERS, NT, NTL, ACT, SPLIT, FULL, GIVEN>), grid, a.threads ? a.threads : GNN_FUSED_THREADS, lds_bytes, st, a);
 }
 
 // a.full_tiles: the host asks for the full-tile specialisation (state width 64); it exists for NTL == 2
@@ -1307,6 +1358,7 @@ template <int LAYERS, int NT, int NTL, int ACT, bool SPLIT>
 inline void launch(const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
     if constexpr (NTL == 2) {
+        if (a.full_tiles && a.agg_in) { launch_one<LAYERS, NT, NTL, ACT, SPLIT, true, true>(a, grid, lds_bytes, st); return; }
         if (a.full_tiles) { launch_one<LAYERS, NT, NTL, ACT, SPLIT, true>(a, grid, lds_bytes, st); return; }
     }
     launch_one<LAYERS, NT, NTL, ACT, SPLIT, false>(a, grid, lds_bytes, st);
