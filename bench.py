@@ -151,9 +151,10 @@ def main():
     ap.add_argument('--impl', type=int, default=2, help='2: fused kernel, split bf16 MFMA (default, what the engine runs by default); '
                                                        '1: fused kernel, bit-exact f32 MFMA; 0: one kernel per TF op')
     ap.add_argument('--act', default='selu', help='net_state activation (experiments; the BASELINE config is selu)')
-    ap.add_argument('--exchange', choices=['full', 'halo', 'slice'], default='full',
-                    help='N > 1: all-gather of whole shards (default), of boundary rows only (gnn_graph_create_halo), or the '
-                         'feature-sliced all-to-all (gnn_loop_set_slice_exchange: every rank aggregates its columns for all nodes)')
+    ap.add_argument('--exchange', choices=['auto', 'full', 'halo', 'slice'], default='auto',
+                    help='N > 1: all-gather of whole shards, of boundary rows only (gnn_graph_create_halo), or the feature-sliced '
+                         'all-to-all (gnn_loop_set_slice_exchange: every rank aggregates its columns for all nodes).  auto: slice '
+                         'from 4 ranks on (2 (P-1)/P^2 instead of (P-1)/P of the state received per iteration), full below')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-iters', type=int, default=20)
     args = ap.parse_args()
@@ -175,6 +176,8 @@ def main():
     ou = make_net(rng, nl + d, [t], 'softmax')
     state0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
 
+    if args.exchange == 'auto':
+        args.exchange = 'slice' if (world >= 4 and d % world == 0) else 'full'
     comm, id_path = None, None
     if world > 1:
         uid, id_path = rendezvous_id(rank, world, engine)

@@ -1421,8 +1421,11 @@ static int slice_alltoall(gnn_loop *l, int which)
         return GNN_OK;
     }
     float *recv = which == 0 ? l->sl_state : l->sl_recv;
+    // the rank's own block is a device copy; the other P - 1 pairs are one grouped send / receive each
+    HIPCHK(hipMemcpyAsync(recv + (size_t)l->rank * block, send + (size_t)l->rank * block, sizeof(float) * block, hipMemcpyDeviceToDevice, l->stream));
     NCCLCHK(g_rccl.GroupStart());
     for (int p = 0; p < l->world; ++p) {
+        if (p == l->rank) continue;
         NCCLCHK(g_rccl.Send(send + (size_t)p * block, block, NCCL_FLOAT32, p, l->comm->nccl, l->stream));
         NCCLCHK(g_rccl.Recv(recv + (size_t)p * block, block, NCCL_FLOAT32, p, l->comm->nccl, l->stream));
     }
