@@ -1182,7 +1182,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS + 4);   // + barrier counter / status of the persistent loop
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 2);        // k, status word of the persistent loop
-    if (!rc) rc = dev_alloc(&l->tile_ctr, (2 * ((size_t)max_iter + 1) + 3) & ~(size_t)3);      // per body: full-tile launch, partial-tile launch
+    if (!rc) rc = dev_alloc(&l->tile_ctr, (2 * ((size_t)max_iter + 1) + 3) & ~(size_t)3);      // one ticket counter per body (the second half is spare: a partial last tile used to get a launch of its own)
     if (!rc && hipHostMalloc((void **)&l->kfinal_host, 2 * sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!rc) l->kfinal_host[1] = 0;
     if (!rc && hipHostMalloc((void **)&l->gate_host, sizeof(int) * (size_t)world * GNN_FLAG_WORDS) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
