@@ -71,6 +71,44 @@ def main():
         go = any_flag(flag)
         k += 1
 
+    # ---- the feature-sliced protocol (gnn_loop_set_slice_exchange) with the same arithmetic: rank q aggregates columns
+    # [q d/P, (q+1) d/P) of ALL nodes over the whole graph's adjacency; two all-to-all steps per iteration; no rank ever holds
+    # another rank's state rows.  Must give the same bits (the fmaf chain of an aggregated element is the same).
+    k_sl, state_sl = None, None
+    if d % world == 0:
+        cs = d // world
+        full = (s['indptr'], s['adj_src'], s['adj_w'])
+
+        def alltoall(blocks):                                   # blocks[q]: [shard, cs] for rank q -> list of what every rank sent me
+            # gloo has no all_to_all: every rank all-gathers its P blocks and keeps the ones addressed to it
+            mine = []
+            gathered = [torch.zeros(world, shard, cs) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(np.stack(blocks).astype(np.float32)))
+            for p_ in range(world):
+                mine.append(gathered[p_][rank].numpy())
+            return mine
+
+        def pad(rows):                                          # [<= shard, w] -> [shard, w]
+            buf = np.zeros((shard, rows.shape[1]), np.float32)
+            buf[:rows.shape[0]] = rows
+            return buf
+
+        own = state0[rb:rb + nr].copy()
+        go = any_flag(orc.not_converged(own, np.ones((nr, d), np.float32), thr).any())
+        k_sl = 0
+        while go and k_sl < max_it:
+            sent = alltoall([pad(own[:, q * cs:(q + 1) * cs]) for q in range(world)])       # my column slice of every rank's rows
+            slice_all = to_global(np.concatenate(sent))                                     # [n, cs]
+            agg_slice = corc.spmm(full, np.ascontiguousarray(slice_all))                     # [n, cs]: all nodes, my columns
+            back = alltoall([pad(agg_slice[ranges[q][0]:ranges[q][0] + ranges[q][1]]) for q in range(world)])       # rank q's rows, my columns
+            agg_own = np.concatenate([b[:nr] for b in back], axis=1)                         # [nr, d]: my rows, all columns
+            inp = np.concatenate([own, s['nodes'][rb:rb + nr], agg_own, agg_nodes, agg_arcs], axis=1)
+            new = corc.mlp_forward(inp, st['weights'], st['activations'], True)
+            go = any_flag(orc.not_converged(new, own, thr).any())
+            own = new
+            k_sl += 1
+        state_sl = gather_state(own)
+
     # single-process oracle on the whole graph
     arcs = np.concatenate([np.stack([s['src'], s['dst']], 1).astype(np.float32), s['arc_labels']], axis=1)
     g = dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
@@ -81,9 +119,11 @@ def main():
     assert len({int(t.item()) for t in ks}) == 1, 'ranks disagree on the iteration count'
     assert k == kc and 1 < k < max_it, (k, kc)
     assert np.array_equal(state, sc), 'sharded state differs from the single-process oracle'
+    if state_sl is not None:
+        assert k_sl == kc and np.array_equal(state_sl, sc), 'feature-sliced protocol differs from the single-process oracle'
     dist.barrier()
     if rank == 0:
-        print(f'SHARDED_OK world={world} k={k}')
+        print(f'SHARDED_OK world={world} k={k} sliced={state_sl is not None}')
     dist.destroy_process_group()
 
 

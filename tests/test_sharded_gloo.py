@@ -15,7 +15,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 4])
 def test_sharded_loop_gloo(world):
     env = dict(os.environ, OMP_NUM_THREADS='2', GNN_ORACLE_THREADS='2')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}', '--master-addr', '127.0.0.1',
@@ -23,6 +23,7 @@ def test_sharded_loop_gloo(world):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert f'SHARDED_OK world={world}' in r.stdout
+    assert f'sliced={world in (2, 4)}' in r.stdout          # state width 8: the feature-sliced protocol runs for worlds that divide it
 
 
 def test_shard_range_properties():
