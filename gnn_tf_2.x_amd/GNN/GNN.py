@@ -188,6 +188,8 @@ class GNNnodeBased(BaseClass):
                      and hasattr(self.optimizer, 'device_step_args'))
         step_args = self.optimizer.device_step_args() if on_device else None
         if step_args is not None:
+            self.net_state.bind_optimizer(self.optimizer)
+            self.net_output.bind_optimizer(self.optimizer)
             bn_s, bn_o = self.net_state.layers[-1], self.net_output.layers[-1]
             loop.arm_optimizer(step_args[0], step_args[1], mean, getattr(bn_s, 'momentum', 0.99), getattr(bn_o, 'momentum', 0.99))
         res = loop.train_step(dev_s, dev_o, None, targets, weights,

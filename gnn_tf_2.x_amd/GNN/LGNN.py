@@ -304,6 +304,8 @@ class LGNN(BaseClass):
                 and not regularizers.any_regularizer(self.get_dense_layers())):
             kind_o, hyper = self.optimizer.device_step_args()           # one optimizer step over all layers (reference :244-247)
             for gnn, loop, k in zip(self.gnns, loops, K):
+                gnn.net_state.bind_optimizer(self.optimizer)
+                gnn.net_output.bind_optimizer(self.optimizer)
                 loop.optimizer_step(kind_o, hyper, (1.0 / k) if (mean and k) else 1.0, getattr(gnn.net_state.layers[-1], 'momentum', 0.99),
                                     getattr(gnn.net_output.layers[-1], 'momentum', 0.99))
                 gnn.net_state.mark_device_newer()

@@ -151,6 +151,14 @@ class Sequential:
             if isinstance(layer, (Dense, BatchNormalization)):
                 layer._owner = self
 
+    def bind_optimizer(self, optimizer):
+        """The device-side slots (Adam moments, SGD velocity) live with the device MLP; a different optimizer object starts from
+        zero slots, as a new tf.keras optimizer would."""
+        if getattr(self, '_slots_of', None) is not optimizer:
+            if getattr(self, '_slots_of', None) is not None and self._device is not None:
+                self._device.reset_optimizer()
+            self._slots_of = optimizer
+
     def mark_device_newer(self):
         """A device-side optimizer step has updated the gnn_mlp's arrays; the host copies are refreshed on their next read."""
         self._host_stale = True

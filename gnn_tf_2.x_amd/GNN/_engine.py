@@ -16,7 +16,7 @@ ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 's
 
 EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_synchronize', 'gnn_graph_create', 'gnn_graph_create_from_arcs',
            'gnn_graph_derive', 'gnn_graph_derive_edge', 'gnn_graph_set_arc_order', 'gnn_graph_update_labels', 'gnn_graph_get_nodes', 'gnn_graph_dims', 'gnn_graph_destroy',
-           'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
+           'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_reset_optimizer', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loop_update_moving_statistics', 'gnn_loss_grad',
            'gnn_loop_set_impl', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
@@ -321,6 +321,10 @@ class Mlp:
         if bn is not None:
             out += [bn[i * f:(i + 1) * f].copy() for i in range(4)]
         return out
+
+    def reset_optimizer(self):
+        """gnn_mlp_reset_optimizer: zero optimizer slots for the next device-side step (a new optimizer object took over)."""
+        _check(lib().gnn_mlp_reset_optimizer(self._h))
 
     def forward(self, x):
         x = _f32(x)

@@ -961,6 +961,16 @@ extern "C" int gnn_mlp_get_weights(gnn_mlp *m, float *const *W, float *const *b,
     return GNN_OK;
 }
 
+extern "C" int gnn_mlp_reset_optimizer(gnn_mlp *m)
+{
+    ARGCHK(m, "mlp is NULL");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipFree(m->opt_a); (void)hipFree(m->opt_b);
+    m->opt_a = nullptr; m->opt_b = nullptr;      // allocated and zeroed again by the next device-side optimizer step
+    return GNN_OK;
+}
+
 extern "C" int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y)
 {
     ARGCHK(m && n_rows >= 0 && (n_rows == 0 || (x && y)), "bad arguments");

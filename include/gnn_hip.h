@@ -108,7 +108,10 @@ int gnn_mlp_set_weights(gnn_mlp *m, const float *const *W, const float *const *b
 int gnn_mlp_forward(gnn_mlp *m, int64_t n_rows, const float *x, float *y);
 /* Sequential.get_weights(): W[l] [dims[l] x dims[l+1]], b[l] [dims[l+1]], bn [4 x width] = gamma | beta | moving_mean |
  * moving_variance (NULL without BatchNormalization); waits for the device first (a device-side optimizer step may be running) */
-int gnn_mlp_get_weights(gnn_mlp *m, float *const *W, float *const *b, float *bn);   /* Sequential.__call__(x, training=False) */
+int gnn_mlp_get_weights(gnn_mlp *m, float *const *W, float *const *b, float *bn);
+/* forget the slots (Adam moments / SGD velocity) of the device-side optimizer: a NEW optimizer object starts from zero, as a
+ * tf.keras optimizer creates its slot variables on first use (reference starter.py:81) */
+int gnn_mlp_reset_optimizer(gnn_mlp *m);   /* Sequential.__call__(x, training=False) */
 int gnn_mlp_destroy(gnn_mlp *m);
 
 /* ---- loop -------------------------------------------------------------------------------------------------------
