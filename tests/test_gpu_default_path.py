@@ -175,7 +175,14 @@ def test_c5_shaped_lgnn_stack():
     K2, state2, outs2 = lgnn2.Loop(go, state0=s0s)
     K64, s64, o64 = orc.lgnn_loop(gd, gnns, False, True, False, s0s, np.float64)
     assert K2 == K64 == K
-    assert np.max(np.abs(state2 - s64)) < 1e-5 and all(np.max(np.abs(a - b)) < 1e-5 for a, b in zip(outs2, o64))
+    diffs = [float(np.max(np.abs(a - b))) for a, b in zip(outs2, o64)] + [float(np.max(np.abs(state2 - s64)))]
+    if not all(x < 1e-5 for x in diffs):
+        # diagnosis for an intermittent failure seen once (normal values: 1.5e-7 per layer, 4.9e-7 for the state): is a second run of the
+        # same objects identical (state of the process) or back to normal (a transient)?
+        K3, state3, outs3 = lgnn2.Loop(go, state0=s0s)
+        again = [float(np.max(np.abs(a - b))) for a, b in zip(outs3, o64)] + [float(np.max(np.abs(state3 - s64)))]
+        raise AssertionError(f'impl 2 vs float64: per-layer output differences + state {diffs}; second run {again}, '
+                             f'bit-identical to the first: {bool(np.array_equal(state2, state3))}; k {K2} / {K3}')
 
 
 def test_config3_depth_fp32_noise_equivalence():
