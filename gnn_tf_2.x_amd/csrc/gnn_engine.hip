@@ -748,6 +748,7 @@ extern "C" int gnn_graph_derive(const gnn_graph *base, int extra, gnn_graph **ou
     g->nodes = nullptr;
     g->arc_labels_own = g->arc_labels_orig_own = nullptr;      // never share the owned arc labels of a derived base
     g->halo_send = nullptr;
+    g->full_indptr = nullptr; g->full_src = nullptr; g->full_w = nullptr; g->full_rows = 0;      // (owned by the base; set again with gnn_graph_set_full_adjacency)
     g->AL = base->base_AL;
     g->nodes_rows = derived_node_rows(g->N);
     int rc = dev_alloc(&g->nodes, (size_t)g->nodes_rows * g->NL);
