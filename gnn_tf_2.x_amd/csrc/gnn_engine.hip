@@ -75,6 +75,17 @@ static int dev_upload(T **p, const T *host, size_t count)
     return GNN_OK;
 }
 
+// Zero a fresh allocation and WAIT for it.  hipMemset on device memory is queued on the null stream and may return before it has
+// run; the loops work on non-blocking streams, which the null stream does not order: a late memset would wipe what a kernel of
+// such a stream has written in the meantime (e.g. k_relabel into the labels of a graph that was derived a moment ago).
+static int dev_zero(void *p, size_t bytes)
+{
+    if (!bytes) return GNN_OK;
+    HIPCHK(hipMemset(p, 0, bytes));
+    HIPCHK(hipDeviceSynchronize());
+    return GNN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------------------------
@@ -752,7 +763,7 @@ extern "C" int gnn_graph_derive(const gnn_graph *base, int extra, gnn_graph **ou
     g->AL = base->base_AL;
     g->nodes_rows = derived_node_rows(g->N);
     int rc = dev_alloc(&g->nodes, (size_t)g->nodes_rows * g->NL);
-    if (!rc && hipMemset(g->nodes, 0, (size_t)g->nodes_rows * g->NL * sizeof(float)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipMemset of the derived node labels failed");
+    if (!rc) rc = dev_zero(g->nodes, (size_t)g->nodes_rows * g->NL * sizeof(float));
     if (rc) { gnn_graph_destroy(g); return rc; }
     *out = g;
     return GNN_OK;
@@ -788,8 +799,8 @@ extern "C" int gnn_graph_derive_edge(const gnn_graph *base, int extra_nodes, int
     g->arc_labels_own = g->arc_labels_orig_own = nullptr;
     rc = dev_alloc(&g->arc_labels_own, (size_t)g->E * g->AL);
     if (!rc) rc = dev_alloc(&g->arc_labels_orig_own, (size_t)g->E * g->AL);
-    if (!rc && (hipMemset(g->arc_labels_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)) != hipSuccess ||
-                hipMemset(g->arc_labels_orig_own, 0, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)) != hipSuccess))
+    if (!rc && (dev_zero(g->arc_labels_own, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)) != GNN_OK ||
+                dev_zero(g->arc_labels_orig_own, std::max<size_t>(1, (size_t)g->E * g->AL) * sizeof(float)) != GNN_OK))
         rc = gnn_fail(GNN_ERR_HIP, "hipMemset of the derived arc labels failed");
     if (rc) { gnn_graph_destroy(g); return rc; }
     *out = g;
@@ -1189,7 +1200,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     for (int i = 1; i <= net_output->n_layers; ++i) maxw_o = std::max(maxw_o, net_output->dims[i]);
     for (int b = 0; b < 2 && !rc; ++b) {
         rc = dev_alloc(&l->state[b], (size_t)l->N_pad * Ds);
-        if (!rc && hipMemset(l->state[b], 0, sizeof(float) * (size_t)l->N_pad * Ds) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "memset");
+        if (!rc) rc = dev_zero(l->state[b], sizeof(float) * (size_t)l->N_pad * Ds);
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS + 4);   // + barrier counter / status of the persistent loop
     if (!rc) rc = dev_alloc(&l->kfinal_dev, 2);        // k, status word of the persistent loop
@@ -1501,7 +1512,7 @@ extern "C" int gnn_loop_set_slice_exchange(gnn_loop *l, int on)
         if (!rc) rc = dev_alloc(&l->sl_recv, slice);
         if (!rc) rc = dev_alloc(&l->agg_own, (size_t)l->shard_rows * l->Ds);
         if (rc) return rc;
-        HIPCHK(hipMemset(l->sl_agg, 0, sizeof(float) * std::max<size_t>(slice, 1)));      // rows past N_global are never written
+        if ((rc = dev_zero(l->sl_agg, sizeof(float) * std::max<size_t>(slice, 1)))) return rc;      // rows past N_global are never written
     }
     l->slice_mode = true;
     return GNN_OK;
