@@ -297,8 +297,9 @@ __global__ void __launch_bounds__(256) k_bn_apply(int64_t n, int F, int cw_shift
         __syncthreads();
     }
     const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
+    const bool small = total < ((int64_t)1 << 31);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const int j = (int)(i % F);
+        const int j = small ? (int)((unsigned)i % (unsigned)F) : (int)(i % F);
         const float xh = (h[i] - sm[j]) * sinv[j];
         xhat[i] = xh;
         y[i] = gamma[j] * xh + beta[j];
@@ -334,8 +335,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_s
     }
     const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
     const float m = (float)n;
+    const bool small = total < ((int64_t)1 << 31);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const int j = (int)(i % F);
+        const int j = small ? (int)((unsigned)i % (unsigned)F) : (int)(i % F);
         const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j];
         float v = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
         if (act >= 0) v = v * act_grad(a[i], act);
@@ -524,7 +526,8 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int f = 0;
     if (i < n * in_s) {
-        const int64_t r = i / in_s;
+        // (a 64-bit division is some forty instructions: the 32-bit one when the matrix has fewer than 2^31 elements)
+        const int64_t r = n * in_s < ((int64_t)1 << 31) ? (int64_t)((unsigned)i / (unsigned)in_s) : i / in_s;
         const int c = (int)(i - r * in_s);
         float v;
         bool skip = false;                         // Ds % 4 == 0: the thread of every fourth aggregate column gathers and writes four
@@ -625,7 +628,7 @@ __global__ void __launch_bounds__(256) k_state_grad_sum(int sg_blocks, int64_t n
     }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * Ds) return;
-    const int64_t r = t / Ds;
+    const int64_t r = n * Ds < ((int64_t)1 << 31) ? (int64_t)((unsigned)t / (unsigned)Ds) : t / Ds;
     const int c = (int)(t - r * Ds);
     float acc = 0.0f;
     const int32_t e1 = sip[r + 1];
