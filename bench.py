@@ -2,6 +2,7 @@
 """Benchmark of the GNN.Loop hot path on MI355X (BASELINE.json metric: node-state-updates/s).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N ...            (bare: this process touches no GPU, starts N rank processes itself and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (BASELINE.json configs[2]): synthetic graph with 1,000,000 nodes and ~10,000,000 directed arcs
@@ -12,14 +13,17 @@ apply_filters, net_output).  Graph, weights and initial state are resident in HB
 
 With N > 1 the SAME graph is sharded by node range (strong scaling): each rank owns N/P destination rows, and every
 iteration ends with one grouped RCCL all-gather of the owned state rows + convergence flag.  No torch in the process: ranks
-read RANK / LOCAL_RANK / WORLD_SIZE from the environment and exchange the RCCL id through a file keyed by the launcher.
+read RANK / LOCAL_RANK / WORLD_SIZE from the environment (set by either launcher) and exchange the RCCL id through a file.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,11 +36,12 @@ for p in (ROOT, os.path.join(ROOT, 'gnn_tf_2.x_amd')):
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def make_net(rng, n_in, widths, act, out_act=None):
-    """Random-init weights of the architecture (lecun_normal-like scale, as starter.py:52-54), BatchNormalization defaults."""
+def make_net(rng, n_in, widths, act, out_act=None, gain=1.0):
+    """Random-init weights of the architecture (lecun_normal-like scale, as starter.py:52-54), BatchNormalization defaults.
+    gain < 1 (other_configs only) makes the state map a contraction, so that Loops converge before max_iteration."""
     w, acts = [], []
     for i, u in enumerate(widths):
-        w += [(rng.standard_normal((n_in, u)) / np.sqrt(n_in)).astype(np.float32), (rng.standard_normal(u) / np.sqrt(u)).astype(np.float32) * 0.1]
+        w += [(gain * rng.standard_normal((n_in, u)) / np.sqrt(n_in)).astype(np.float32), (rng.standard_normal(u) / np.sqrt(u)).astype(np.float32) * 0.1]
         acts.append(out_act if (out_act and i == len(widths) - 1) else act)
         n_in = u
     w += [np.ones(n_in, np.float32), np.zeros(n_in, np.float32), np.zeros(n_in, np.float32), np.ones(n_in, np.float32)]
@@ -51,13 +56,18 @@ def algorithmic_bytes_per_iteration(n, e, ds, nl, al):
 
 def rendezvous_id(rank, world, engine):
     """Rank 0 creates the RCCL unique id; the others read it from a file keyed by the launcher process (same parent)."""
+    if os.environ.get('GNN_BENCH_RDV'):                   # bare `bench.py --gpus N`: the launcher names the file
+        return _rendezvous_file(os.environ['GNN_BENCH_RDV'], rank, engine)
     ppid = os.getppid()
     try:
         with open(f'/proc/{ppid}/stat') as f:
             start = f.read().rsplit(')', 1)[1].split()[19]
     except Exception:
         start = '0'
-    path = f'/tmp/gnn_rccl_{ppid}_{start}_{os.environ.get("MASTER_PORT", "0")}_{world}.id'
+    return _rendezvous_file(f'/tmp/gnn_rccl_{ppid}_{start}_{os.environ.get("MASTER_PORT", "0")}_{world}.id', rank, engine)
+
+
+def _rendezvous_file(path, rank, engine):
     if rank == 0:
         uid = engine.Comm.unique_id()
         with open(path + '.tmp', 'wb') as f:
@@ -80,7 +90,7 @@ def oracle_graph(s):
                 adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
 
 
-def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0):
+def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0, full=None):
     """The plain-C restatement of the TF2 op sequence (oracle/gnn_oracle.c: CSR SpMM -> materialised concat -> Dense x3 ->
     BatchNormalization -> norm check), OpenMP over all host cores, on a bounded sample: the full graph, `iters` iterations;
     a second figure with the sparse products on ONE thread (TensorFlow's CPU SparseTensorDenseMatMul is believed to be
@@ -91,7 +101,7 @@ def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0):
     g = oracle_graph(s)
     c_oracle.loop_node(g, st, ou, d, 1, 0.0, state0)     # warm-up (page faults, thread pool)
     t = time.perf_counter()
-    k, _, _ = c_oracle.loop_node(g, st, ou, d, iters, 0.0, state0)
+    k, s_orc, o_orc = c_oracle.loop_node(g, st, ou, d, iters, 0.0, state0)
     dt = time.perf_counter() - t
     c_oracle.set_spmm_single_thread(True)
     t1 = time.perf_counter()
@@ -103,6 +113,23 @@ def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0):
                       f'(not TensorFlow itself), OpenMP, {dt:.1f} s',
                single_thread_spmm={'value': n * k1 / dt1, 'sample': f'{int(k1)} iterations, sparse products on 1 thread, dense layers on '
                                                                      f'{c_oracle.num_threads()}, {dt1:.1f} s'})
+    if full is not None:
+        # the oracle is the checker: the GPU Loop on the SAME graph / weights / state0 for the same number of bodies, compared with
+        # the oracle state that was just timed - all N x 64 values (impl 1: bit for bit; default path: max |difference|)
+        graph, mst, mou = full
+        chk = {'iterations': int(k), 'oracle_max_abs_state': float(np.max(np.abs(s_orc)))}
+        for impl, name in ((1, 'exact_f32_mfma_path'), (2, 'default_split_bf16_path')):
+            lp = engine.Loop(graph, mst, mou, d, int(iters), 0.0)
+            lp.set_impl(impl)
+            lp.set_state0(state0)
+            k_gpu = lp.run()
+            sg, og_ = lp.state(), lp.output()
+            lp.close()
+            chk[name] = {'k_equal': bool(k_gpu == k), 'bit_identical_state': bool(np.array_equal(sg, s_orc)),
+                         'max_abs_diff_state': float(np.max(np.abs(sg - s_orc))), 'max_abs_diff_output': float(np.max(np.abs(og_ - o_orc)))}
+            del sg, og_
+        out['gpu_vs_oracle_full_size'] = chk
+    del s_orc, o_orc
     if engine is not None:
         from GNN import GNN_utils as utils
         n2, bodies = 50_000, 30
@@ -124,6 +151,139 @@ def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0):
             lp.close()
         dist['graph'] = f'{n2} nodes / {s2["n_arcs"]} arcs, same generator and weights, {bodies} bodies (threshold 0), max |state| {float(np.max(np.abs(s64))):.2f}'
         out['fp32_noise_check'] = dist
+    return out
+
+
+def launch_ranks(n, argv, worker=None, grace_s=10.0):
+    """Parent of a bare `python bench.py --gpus N` (N > 1).  It makes NO GPU call (the engine is not even imported here): it
+    starts N fresh rank processes - RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, the RCCL
+    id exchanged through the file named by GNN_BENCH_RDV - waits for them, relays rank 0's JSON line on stdout and returns 0;
+    if any rank fails it stops the others (by their exact pids) and returns that rank's exit code.  `worker`: command prefix of a
+    rank (default: this interpreter on this file); tests pass a stub."""
+    worker = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    tmp = tempfile.mkdtemp(prefix='gnn_bench_')
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), GNN_BENCH_RDV=os.path.join(tmp, 'rccl.id'))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs, outs = [], []
+    for r in range(n):
+        out = open(os.path.join(tmp, f'rank{r}.out'), 'w+')
+        outs.append(out)
+        procs.append(subprocess.Popen(worker + list(argv), env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=out))      # stderr: inherited
+    rc, live = 0, set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code
+                print(f'bench.py: rank {r} of {n} exited with code {code}; stopping the other ranks', file=sys.stderr, flush=True)
+                break
+        time.sleep(0.05)
+    if rc != 0:
+        for r in live:
+            procs[r].terminate()
+        deadline = time.time() + grace_s
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    outs[0].seek(0)
+    text0 = outs[0].read()
+    for r, out in enumerate(outs):
+        if r:                                   # ranks > 0 print nothing on stdout normally; whatever they did goes to stderr
+            out.seek(0)
+            extra = out.read()
+            if extra.strip(): print(f'[rank {r} stdout] {extra}', file=sys.stderr)
+        out.close()
+    for name in os.listdir(tmp):
+        os.remove(os.path.join(tmp, name))
+    os.rmdir(tmp)
+    if rc == 0:
+        lines = [ln for ln in text0.splitlines() if ln.startswith('{')]
+        if not lines:
+            print(f'bench.py: rank 0 printed no JSON line; its stdout was: {text0[-2000:]!r}', file=sys.stderr)
+            return 1
+        for ln in text0.splitlines():
+            if not ln.startswith('{') and ln.strip(): print(ln, file=sys.stderr)
+        print(lines[-1], flush=True)
+    elif text0.strip():
+        print(text0, file=sys.stderr)
+    return rc
+
+
+def other_configs(engine, s, device=0):
+    """The other BASELINE configs on this GPU, after the timed region (never part of `value`): configs[1] MUTAG batches of 32 graphs
+    (gnn_loop_run - the persistent one-launch loop - plus the NodeGraph readout, as GNNgraphBased.Loop does), and configs[4] the
+    5-layer LGNN stack on the 1M-node graph (get_state=False, get_output=True: labels widened by 2; relabelling on the device)."""
+    from GNN.graph_class import GraphObject, GraphTensor
+    import load_MUTAG
+    out = {}
+    rng = np.random.default_rng(1)
+    # ---- configs[1]: MUTAG, net_state 31 -> 32 -> 32 -> 14 (D = 0), net_output 14 -> 2, max_iter 50, threshold 0.01 --------------
+    graphs = load_MUTAG.load(limit=320)
+    batches = [GraphTensor.fromGraphObject(GraphObject.merge(graphs[i:i + 32], problem_based='g', aggregation_mode='average')) for i in range(0, 320, 32)]
+    st, ou = make_net(rng, 31, [32, 32, 14], 'selu', gain=0.7), make_net(rng, 14, [2], 'softmax')
+    mst, mou = engine.Mlp(st['weights'], st['activations'], True, device=device), engine.Mlp(ou['weights'], ou['activations'], True, device=device)
+    loops = []
+    for b in batches:
+        lp = engine.Loop(b.device_graph(device), mst, mou, 0, 50, 0.01)
+        loops.append((lp, b.nodegraph_csr(), b.nodes.shape[0]))
+    persistent = all(lp.set_persistent(True) for lp, _, _ in loops)
+    for lp, ng, _ in loops:
+        lp.run(); lp.readout(*ng)
+    reps, iters, updates = 30, 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for lp, ng, nn in loops:
+            k = lp.run()
+            lp.readout(*ng)
+            iters += k; updates += k * nn
+    dt = time.perf_counter() - t0
+    out['mutag_batch32'] = {'loops_per_s': reps * len(loops) / dt, 'graphs_per_s': 32 * reps * len(loops) / dt, 'node_state_updates_per_s': updates / dt,
+                            'mean_iterations': iters / (reps * len(loops)), 'persistent_one_launch_loop': bool(persistent),
+                            'what': 'BASELINE configs[1] shape: 10 batches of 32 MUTAG graphs (~570 nodes each), net_state 31->32->32->14, max_iter 50, '
+                                    'threshold 0.01, GNN.Loop + NodeGraph readout per batch, host-timed'}
+    for lp, _, _ in loops: lp.close()
+    # ---- configs[4]: LGNN x 5 on the bench graph ----------------------------------------------------------------------------------
+    layers, d, nl, al, t, max_it = 5, 64, 3, 1, 2, 30
+    n = s['n_nodes']
+    base = engine.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8), device=device)
+    derived = base.derive(t)
+    stack = []
+    rng = np.random.default_rng(7)
+    for layer in range(layers):
+        nll = nl + (t if layer else 0)
+        st, ou = make_net(rng, al + 2 * (nll + d), [128, 128, d], 'selu'), make_net(rng, nll + d, [t], 'softmax')
+        lp = engine.Loop(base if layer == 0 else derived, engine.Mlp(st['weights'], st['activations'], True, device=device),
+                         engine.Mlp(ou['weights'], ou['activations'], True, device=device), d, max_it, 0.0)
+        lp.set_state0(None, seed=layer + 1)              # drawn on the device: N(0, 0.1^2)
+        stack.append(lp)
+
+    def run_stack():
+        ks = 0.0
+        for layer, lp in enumerate(stack):
+            ks += lp.run()
+            if layer < layers - 1:
+                derived.update_labels(base, lp, False, True)
+        return ks
+
+    run_stack()
+    reps = 3
+    t0 = time.perf_counter()
+    ks = sum(run_stack() for _ in range(reps))
+    dt = time.perf_counter() - t0
+    out['lgnn_x5_1M'] = {'ms_per_lgnn_loop': 1e3 * dt / reps, 'iterations_per_lgnn_loop': ks / reps, 'node_state_updates_per_s': n * ks / dt,
+                         'what': 'BASELINE configs[4]: 5 stacked GNN.Loops (30 bodies each, threshold 0) on the 1M-node graph, labels of layers 1-4 '
+                                 'widened by the previous output (139->128->128->64 / 69->2), relabelling on the device, host-timed'}
+    for lp in stack: lp.close()
+    derived.close(); base.close()
     return out
 
 
@@ -156,16 +316,22 @@ def main():
                          'all-to-all (gnn_loop_set_slice_exchange: every rank aggregates its columns for all nodes).  auto: slice '
                          'from 4 ranks on (2 (P-1)/P^2 instead of (P-1)/P of the state received per iteration), full below')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the untimed configs[1] / configs[4] figures under config.other_configs')
     ap.add_argument('--cpu-iters', type=int, default=20)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # bare multi-GPU invocation: become the launcher (no GPU call in this process)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {args.gpus}` bare (it starts its own ranks) '
+                         f'or under torch.distributed.run --nproc-per-node {args.gpus}')
 
     from GNN import _engine as engine, GNN_utils as utils
+    if engine.device_count() < max(world, local_rank + 1):
+        raise SystemExit(f'bench.py --gpus {world}: needs {world} devices, {engine.device_count()} visible (rank {rank})')
     engine.require_device(local_rank)
 
     d, nl, al, t = 64, 3, 1, 2
@@ -303,8 +469,10 @@ def main():
         if pf:      # counters of the same kernel from the committed PMC passes (north_star: HBM GB/s and MFMA-busy against gfx950 peak)
             line['roofline'].update({k: pf[k] for k in ('mfma_busy_pct', 'valu_busy_pct', 'lds_bank_conflict_share', 'valu_insts_per_tile',
                                                         'effective_clock_ghz', 'profiled_avg_launch_ms') if k in pf})
+        if world == 1 and not args.no_other_configs and args.nodes == 1_000_000:
+            line['config']['other_configs'] = other_configs(engine, s, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters, engine, local_rank)
+            line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters, engine, local_rank, full=(graph, mst, mou))
         print(json.dumps(line), flush=True)
     if comm:
         barrier()

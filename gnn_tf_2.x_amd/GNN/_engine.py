@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgnn_hip.so')
+# GNN_HIP_LIBRARY: another build of the same library (the diagnostic build `make DIAG=1` -> libgnn_hip_diag.so); never a fallback
+LIB_PATH = os.environ.get('GNN_HIP_LIBRARY') or os.path.join(_HERE, 'libgnn_hip.so')
 
 ACT_CODES = {'linear': 0, None: 0, 'relu': 1, 'selu': 2, 'elu': 3, 'tanh': 4, 'sigmoid': 5, 'softmax': 6}
 

@@ -145,6 +145,9 @@ struct gnn_graph {
     int32_t *full_indptr = nullptr, *full_src = nullptr;
     float *full_w = nullptr;
     int64_t full_rows = 0;
+    // recorded behind the creation-time zero fills of a derived graph's label arrays (engine fill stream); streams that touch the
+    // labels wait for it on the device (gnn_graph_wait_ready), host readers synchronise on it.  nullptr: nothing to wait for.
+    hipEvent_t ready = nullptr;
 };
 
 inline const float *gnn_graph_arc_labels(const gnn_graph *g) { return g->arc_labels_own ? g->arc_labels_own : g->sh->arc_labels; }
@@ -215,6 +218,7 @@ struct gnn_loop {
     bool small_disabled = false;            // the persistent small-graph loop gave up once on this loop: keep to per-body launches
     int kfinal = -1;
     bool have_state0 = false, ran = false;
+    bool graph_ready_seen = false;          // this loop's stream has waited for the graph's creation-time fills
     int impl_req = 1, impl_used = 0;
     int32_t *ng_ip = nullptr, *ng_node = nullptr;   // cached NodeGraph^T (graph readout)
     float *ng_w = nullptr, *ng_out = nullptr, *ng_part = nullptr;   // ng_part [world, G, T]: per-rank partial readouts
@@ -244,6 +248,7 @@ struct gnn_loop {
 };
 
 // gnn_engine.hip
+int gnn_graph_wait_ready(const gnn_graph *g, hipStream_t st);
 int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const int32_t *idx, const float *w, const float *X,
                     int width, int64_t ldx, float *out, int64_t ldo, const int *gate, int world);
 

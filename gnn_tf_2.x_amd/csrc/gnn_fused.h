@@ -56,8 +56,8 @@ struct GnnSmallCtl {
     const float *init;       // initial state of the owned rows [n_rows, Ds] (injected / drawn state, or the node labels for D == 0)
     int *kfinal;             // receives the number of executed bodies
     int *flags;              // word [b]: barrier + gate of body b (low half arrivals, high half movers), zeroed before the launch
-    int *status;             // = kfinal + 1: set to 1 by a workgroup whose barrier spin gave up, to 0 at the regular end
-    int *host_result;        // pinned host memory (zero-copy): [k, status] for the host, or nullptr
+    int *status;             // = kfinal + 1: set to 1 by a workgroup whose barrier spin gave up; never cleared by the kernel (sticky), zeroed by the host before the launch
+    int *host_result;        // pinned host memory (zero-copy): [k, status] for the host, or nullptr; status as above: host clears, kernel only sets
     int *zero_words;         // the OTHER run's gate words (double-buffered by run parity): zeroed here for the next run
     int n_words;
     int max_iter;

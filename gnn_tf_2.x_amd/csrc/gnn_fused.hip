@@ -385,6 +385,8 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     // and zeroes the other half for the next run, so a run costs no memset; both halves are cleared by the host only after
     // something else (a per-body run) has used the block.
     const size_t n_words = ((size_t)l->max_iter + 2 + 3) & ~(size_t)3;
+    l->kfinal_host[1] = 0;                                            // status: cleared HERE, only ever set by the kernel (sticky)
+    HIPCHK(hipMemsetAsync(l->kfinal_dev + 1, 0, sizeof(int), l->stream));
     if (!l->small_words_clean) {
         HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * 2 * n_words, l->stream));
         l->small_words_clean = true;

@@ -135,7 +135,13 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         }
         seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
         if (seen == 0xffffffffu) {
-            if (lane == 0) __hip_atomic_store((GNN_GLOBAL int *)c.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // STICKY failure: the kernel only ever SETS the status words (the host clears them before the launch, gnn_small_run).  A
+            // workgroup that gives up has already added itself to the barrier word, so a late arrival can still complete that barrier
+            // for the others; if it is the last one they finish normally - and must not overwrite this 1 with a 0.
+            if (lane == 0) {
+                __hip_atomic_store((GNN_GLOBAL int *)c.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c.host_result) c.host_result[1] = 1;
+            }
             return -1;
         }
         return (seen >> 16) ? 1 : 0;
@@ -217,13 +223,10 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         go = arrive_and_gate(k + 1, moved);
         SMALL_STAMP();                                               // body + 3: barrier + gate
     }
-    if (go < 0) {
-        if (c.host_result && lane == 0) c.host_result[1] = 1;
-        return;
-    }
-    if (blockIdx.x == 0 && lane == 0) {      // executed bodies (GNN.py:267; every workgroup agrees), status ok
-        c.kfinal[0] = k; c.kfinal[1] = 0;
-        if (c.host_result) { c.host_result[0] = k; c.host_result[1] = 0; }
+    if (go < 0) return;                      // (status words already set, see arrive_and_gate; this tile's output rows stay stale: the host repeats the Loop)
+    if (blockIdx.x == 0 && lane == 0) {      // executed bodies (GNN.py:267; every workgroup agrees).  The status words are NOT touched here.
+        c.kfinal[0] = k;
+        if (c.host_result) c.host_result[0] = k;
     }
     // ---- apply_filters + one-layer net_output on the tile's masked rows (GNN.py:275-279), arithmetic as k_out1: k-ordered fmaf
     // chain per output, bias, softmax / activation, BatchNormalization ------------------------------------------------------

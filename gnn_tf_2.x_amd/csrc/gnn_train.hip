@@ -1231,8 +1231,13 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     gnn_graph *g = l->g;
     const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked, E = g->E;
     const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->ou->dims[0];
+    int rc0 = 0;
     HIPCHK(hipSetDevice(l->device));
     hipStream_t st = l->stream;
+    if (!l->graph_ready_seen) {      // creation-time fills of a derived graph's labels come before their first read (gnn_graph_wait_ready)
+        if ((rc0 = gnn_graph_wait_ready(g, st))) return rc0;
+        l->graph_ready_seen = true;
+    }
     gnn_train_ctx_free(l);
     if (!l->train_arena) l->train_arena = new TrainArena();
     TrainArena *arena = static_cast<TrainArena *>(l->train_arena);
