@@ -229,7 +229,14 @@ def other_configs(engine, s, device=0):
     # ---- configs[1]: MUTAG, net_state 31 -> 32 -> 32 -> 14 (D = 0), net_output 14 -> 2, max_iter 50, threshold 0.01 --------------
     graphs = load_MUTAG.load(limit=320)
     batches = [GraphTensor.fromGraphObject(GraphObject.merge(graphs[i:i + 32], problem_based='g', aggregation_mode='average')) for i in range(0, 320, 32)]
-    st, ou = make_net(rng, 31, [32, 32, 14], 'selu', gain=0.7), make_net(rng, 14, [2], 'softmax')
+    def net(n_in, widths, act, gain):          # the weights tools/bench_small.py has always used (tests/util.make_mlp), so that rounds stay comparable
+        w, d_ = [], n_in
+        for u in widths:
+            w += [(gain * rng.standard_normal((d_, u)) / np.sqrt(d_)).astype(np.float32), (rng.standard_normal(u) / np.sqrt(d_)).astype(np.float32)]
+            d_ = u
+        return dict(weights=w + [np.ones(d_, np.float32), np.zeros(d_, np.float32), np.zeros(d_, np.float32), np.ones(d_, np.float32)],
+                    activations=[act] * len(widths), batch_normalization=True)
+    st, ou = net(31, [32, 32, 14], 'selu', 0.7), net(14, [2], 'softmax', 1.0)
     mst, mou = engine.Mlp(st['weights'], st['activations'], True, device=device), engine.Mlp(ou['weights'], ou['activations'], True, device=device)
     loops = []
     for b in batches:
@@ -247,7 +254,7 @@ def other_configs(engine, s, device=0):
             iters += k; updates += k * nn
     dt = time.perf_counter() - t0
     out['mutag_batch32'] = {'loops_per_s': reps * len(loops) / dt, 'graphs_per_s': 32 * reps * len(loops) / dt, 'node_state_updates_per_s': updates / dt,
-                            'mean_iterations': iters / (reps * len(loops)), 'persistent_one_launch_loop': bool(persistent),
+                            'mean_iterations': iters / (reps * len(loops)), 'us_per_iteration': 1e6 * dt / iters, 'persistent_one_launch_loop': bool(persistent),
                             'what': 'BASELINE configs[1] shape: 10 batches of 32 MUTAG graphs (~570 nodes each), net_state 31->32->32->14, max_iter 50, '
                                     'threshold 0.01, GNN.Loop + NodeGraph readout per batch, host-timed'}
     for lp, _, _ in loops: lp.close()

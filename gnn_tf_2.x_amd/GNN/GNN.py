@@ -199,6 +199,7 @@ class GNNnodeBased(BaseClass):
                               bn_state=None if step_args is not None else self.net_state.bn_gamma_beta(),
                               bn_output=None if step_args is not None else self.net_output.bn_gamma_beta())
         if step_args is not None:
+            self.optimizer.device_step_done()          # counted only now: a failed step (exception above) leaves t where it was
             self.net_state.mark_device_newer()
             self.net_output.mark_device_newer()
             return res

@@ -310,6 +310,7 @@ class LGNN(BaseClass):
                                     getattr(gnn.net_output.layers[-1], 'momentum', 0.99))
                 gnn.net_state.mark_device_newer()
                 gnn.net_output.mark_device_newer()
+            self.optimizer.device_step_done()
             return dict(loss=loss, k=K, grads_state=[r['grads_state'] for r in results], grads_output=[r['grads_output'] for r in results], outs=outs)
         for gnn, r in zip(self.gnns, results):     # regularizer terms of the taped loss (reference GNN_BaseClass.py:223-235)
             for net, key in ((gnn.net_state, 'grads_state'), (gnn.net_output, 'grads_output')):

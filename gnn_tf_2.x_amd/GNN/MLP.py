@@ -154,10 +154,12 @@ class Sequential:
     def bind_optimizer(self, optimizer):
         """The device-side slots (Adam moments, SGD velocity) live with the device MLP; a different optimizer object starts from
         zero slots, as a new tf.keras optimizer would."""
-        if getattr(self, '_slots_of', None) is not optimizer:
-            if getattr(self, '_slots_of', None) is not None and self._device is not None:
+        key = (optimizer, getattr(optimizer, '_slot_token', None))      # the token changes when the optimizer restarts (path switch)
+        old = getattr(self, '_slots_of', None)
+        if old is None or old[0] is not key[0] or old[1] is not key[1]:
+            if old is not None and self._device is not None:
                 self._device.reset_optimizer()
-            self._slots_of = optimizer
+            self._slots_of = key
 
     def mark_device_newer(self):
         """A device-side optimizer step has updated the gnn_mlp's arrays; the host copies are refreshed on their next read."""

@@ -4,12 +4,31 @@ import numpy as np
 
 
 class Optimizer:
+    """Slots (Adam moments, SGD velocity) live either on the device (with the gnn_mlp: gnn_loop_optimizer_step) or on the host
+    (apply_gradients), the step counter here.  A model that changes path (a regularizer appears, device_optimizer is toggled) restarts
+    BOTH together - slots and counter - like a new Keras optimizer would; `_slot_token` changes then, which makes Sequential.bind_optimizer
+    zero the device slots."""
+    _path = None
+    _slot_token = None
+
     def get_config(self):
         return dict(self._config)
 
+    def reset(self):
+        self._slot_token = object()
+
+    def _enter(self, path):
+        if self._path is not None and self._path != path:
+            self.reset()
+        self._path = path
+
     def device_step_args(self):
-        """(kind, hyper[<= 4]) of include/gnn_hip.h:gnn_loop_arm_optimizer for the NEXT step, counting it; None: host only."""
+        """(kind, hyper[<= 4]) of include/gnn_hip.h:gnn_loop_arm_optimizer for the NEXT step; None: host only.  The step is counted by
+        device_step_done() once it has succeeded (a failed gnn_loop_train_step must not advance the bias correction)."""
         return None
+
+    def device_step_done(self):
+        pass
 
     def apply_gradients(self, grads_and_vars):
         """[(grad, array)] -> list of updated arrays, in order (arrays are identified by position across calls)."""
@@ -24,13 +43,21 @@ class Adam(Optimizer):
         self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         self.iterations, self._m, self._v = 0, None, None
 
+    def reset(self):
+        super().reset()
+        self.iterations, self._m, self._v = 0, None, None
+
     def device_step_args(self):
-        self.iterations += 1
-        t = self.iterations
+        self._enter('device')
+        t = self.iterations + 1
         lr_t = self.learning_rate * np.sqrt(1 - self.beta_2 ** t) / (1 - self.beta_1 ** t)
         return 1, [lr_t, self.beta_1, self.beta_2, self.epsilon]
 
+    def device_step_done(self):
+        self.iterations += 1
+
     def apply_gradients(self, grads_and_vars):
+        self._enter('host')
         grads_and_vars = list(grads_and_vars)
         if self._m is None:
             self._m = [np.zeros_like(p, dtype=np.float64) for _, p in grads_and_vars]
@@ -52,10 +79,16 @@ class SGD(Optimizer):
         self._config = dict(learning_rate=learning_rate, momentum=momentum)
         self.learning_rate, self.momentum, self._vel = learning_rate, momentum, None
 
+    def reset(self):
+        super().reset()
+        self._vel = None
+
     def device_step_args(self):
+        self._enter('device')
         return 0, [self.learning_rate, self.momentum]
 
     def apply_gradients(self, grads_and_vars):
+        self._enter('host')
         grads_and_vars = list(grads_and_vars)
         if self._vel is None:
             self._vel = [np.zeros_like(p, dtype=np.float64) for _, p in grads_and_vars]

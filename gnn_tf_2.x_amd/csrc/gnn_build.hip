@@ -127,6 +127,12 @@ extern "C" int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const
     g->sh = new gnn_graph_shared();
     gnn_graph_shared *sh = g->sh;
     auto fail = [&](int code) { gnn_graph_destroy(g); return code; };
+    // from here on a failing HIP call releases the half-built handle (HIPCHK alone would leak it)
+#define HIPCHK_G(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(gnn_fail(GNN_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)));    \
+    } while (0)
     if ((rc = keep(&sh->indptr, N + 1)) || (rc = keep(&sh->adj_src, E)) || (rc = keep(&sh->adj_w, E)) || (rc = keep(&sh->arc_w, E)) ||
         (rc = keep(&sh->arc_labels, (size_t)E * AL)))
         return fail(rc);
@@ -158,13 +164,13 @@ extern "C" int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const
             return fail(gnn_fail(GNN_ERR_HIP, "hipcub sort failed"));
         hipLaunchKernelGGL(k_permute_adj, cdiv(E, 256), 256, 0, 0, E, d_perm1, d_src, d_w, sh->adj_src, sh->adj_w);
         hipLaunchKernelGGL(k_permute_arc, cdiv(E * (AL > 0 ? AL : 1), 256), 256, 0, 0, E, AL, d_perm2, d_w, d_lab, sh->arc_w, sh->arc_labels);
-        HIPCHK(hipGetLastError());
+        HIPCHK_G(hipGetLastError());
     }
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK_G(hipStreamSynchronize(nullptr));        // everything above ran on the null stream, in order: no device-wide wait
 
     // what stays on the host side of the handle: the row list of the mask and the maximum in-degree
     std::vector<int32_t> indptr((size_t)N + 1);
-    HIPCHK(hipMemcpy(indptr.data(), sh->indptr, sizeof(int32_t) * (N + 1), hipMemcpyDeviceToHost));
+    HIPCHK_G(hipMemcpy(indptr.data(), sh->indptr, sizeof(int32_t) * (N + 1), hipMemcpyDeviceToHost));
     if (indptr[N] != E) return fail(gnn_fail(GNN_ERR_HIP, "device build: indptr[N]=%d but %lld arcs", indptr[N], (long long)E));
     int maxdeg = 0;
     for (int64_t r = 0; r < N; ++r) maxdeg = std::max(maxdeg, indptr[r + 1] - indptr[r]);
@@ -175,18 +181,19 @@ extern "C" int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const
     std::vector<int32_t> both(rows);
     both.insert(both.end(), pos.begin(), pos.end());
     if ((rc = keep(&sh->mask, N)) || (rc = keep(&sh->masked_rows, both.size())) || (rc = keep(&g->nodes, (size_t)N * dim_node_label))) return fail(rc);
-    HIPCHK(hipMemcpy(sh->mask, mask, (size_t)N, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(sh->masked_rows, both.data(), sizeof(int32_t) * both.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g->nodes, nodes, sizeof(float) * (size_t)N * dim_node_label, hipMemcpyHostToDevice));
+    HIPCHK_G(hipMemcpy(sh->mask, mask, (size_t)N, hipMemcpyHostToDevice));
+    HIPCHK_G(hipMemcpy(sh->masked_rows, both.data(), sizeof(int32_t) * both.size(), hipMemcpyHostToDevice));
+    HIPCHK_G(hipMemcpy(g->nodes, nodes, sizeof(float) * (size_t)N * dim_node_label, hipMemcpyHostToDevice));
 
     // host mirrors for the caller (GraphTensor keeps them like the reference keeps its SparseTensors); any may be NULL
     if (indptr_out) memcpy(indptr_out, indptr.data(), sizeof(int32_t) * (N + 1));
     if (E) {
-        if (adj_src_out) HIPCHK(hipMemcpy(adj_src_out, sh->adj_src, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
-        if (adj_w_out) HIPCHK(hipMemcpy(adj_w_out, sh->adj_w, sizeof(float) * E, hipMemcpyDeviceToHost));
-        if (arc_id_out) HIPCHK(hipMemcpy(arc_id_out, d_perm2, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
-        if (arc_w_out) HIPCHK(hipMemcpy(arc_w_out, sh->arc_w, sizeof(float) * E, hipMemcpyDeviceToHost));
+        if (adj_src_out) HIPCHK_G(hipMemcpy(adj_src_out, sh->adj_src, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
+        if (adj_w_out) HIPCHK_G(hipMemcpy(adj_w_out, sh->adj_w, sizeof(float) * E, hipMemcpyDeviceToHost));
+        if (arc_id_out) HIPCHK_G(hipMemcpy(arc_id_out, d_perm2, sizeof(int32_t) * E, hipMemcpyDeviceToHost));
+        if (arc_w_out) HIPCHK_G(hipMemcpy(arc_w_out, sh->arc_w, sizeof(float) * E, hipMemcpyDeviceToHost));
     }
     *out = g;
     return GNN_OK;
+#undef HIPCHK_G
 }

@@ -1168,6 +1168,7 @@ extern "C" int gnn_comm_allreduce_max(gnn_comm *c, double *value)
 extern "C" int gnn_comm_destroy(gnn_comm *c)
 {
     if (!c) return GNN_OK;
+    if (c->loops > 0) { c->closed = true; return GNN_OK; }      // released by the last gnn_loop_destroy
     (void)hipSetDevice(c->device);
     if (c->grp) {
         if (--c->grp->refs == 0) { (void)hipStreamDestroy(c->grp->stream); delete c->grp; }
@@ -1223,6 +1224,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
 
     HIPCHK(hipSetDevice(g->device));
     gnn_loop *l = new gnn_loop();
+    if (comm) comm->loops++;                 // (gnn_loop_destroy, also on the failure paths below, gives it back)
     l->g = g; l->st = net_state; l->ou = net_output; l->comm = comm; l->device = g->device; l->rank = rank; l->world = world;
     l->D = state_dim; l->Ds = Ds; l->NLc = NLc; l->in_s = in_s; l->wf = Ds + NLc; l->T = net_output->dims.back();
     l->max_iter = max_iter; l->thr = threshold;
@@ -1234,7 +1236,7 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
     if (comm) l->stream = comm->stream;
     else {
         hipError_t e = hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete l; return gnn_fail(GNN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { gnn_loop_destroy(l); return gnn_fail(GNN_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
     }
     int maxw_s = 1, maxw_o = 1;
     for (int i = 1; i <= net_state->n_layers; ++i) maxw_s = std::max(maxw_s, net_state->dims[i]);
@@ -1314,6 +1316,24 @@ extern "C" int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *av
     if (total_ms) *total_ms = l->total_ms;
     if (avg_iter_ms) *avg_iter_ms = l->avg_iter_ms;
     if (n_iter_timed) *n_iter_timed = l->n_iter_timed;
+    return GNN_OK;
+}
+
+extern "C" int gnn_counters_get(const gnn_loop *l, double *bytes_per_iteration, double *flops_per_iteration, int *iterations, float *total_ms,
+                                float *avg_iteration_ms)
+{
+    ARGCHK(l, "loop is NULL");
+    const gnn_graph *g = l->g;
+    const double n = (double)g->n_rows, e = (double)g->E, ds = (double)l->Ds;
+    if (bytes_per_iteration) *bytes_per_iteration = e * (4.0 * ds + 8.0) + 4.0 * (n + 1.0) + n * (8.0 * ds + 4.0 * (2.0 * l->NLc + g->AL));
+    if (flops_per_iteration) {
+        double f = 0.0;
+        for (int i = 0; i < l->st->n_layers; ++i) f += 2.0 * (double)l->st->dims[i] * (double)l->st->dims[i + 1];
+        *flops_per_iteration = n * f + 2.0 * e * ds;
+    }
+    if (iterations) *iterations = l->ran ? l->kfinal : 0;
+    if (total_ms) *total_ms = l->ran ? l->total_ms : 0.f;
+    if (avg_iteration_ms) *avg_iteration_ms = l->ran ? l->avg_iter_ms : 0.f;
     return GNN_OK;
 }
 
@@ -1809,6 +1829,11 @@ extern "C" int gnn_loop_run_group(gnn_loop **loops, int n, float *k_out)
         ARGCHK(loops[r] && loops[r]->comm && loops[r]->comm->grp, "loops[%d] was not created on a loopback communicator", r);
         ARGCHK(loops[r]->comm->grp == loops[0]->comm->grp && loops[r]->world == n && loops[r]->rank == r, "loops must be the %d ranks of one loopback group, in rank order", n);
         ARGCHK(loops[r]->max_iter == loops[0]->max_iter && loops[r]->thr == loops[0]->thr && loops[r]->Ds == loops[0]->Ds, "ranks were configured differently");
+        // the exchange protocol of the whole group follows rank 0: a rank on another layout / arithmetic would skip or misread an exchange
+        ARGCHK(loops[r]->slice_mode == loops[0]->slice_mode && loops[r]->Cs == loops[0]->Cs && loops[r]->impl_req == loops[0]->impl_req &&
+               (loops[r]->g->halo_world != 0) == (loops[0]->g->halo_world != 0),
+               "rank %d uses another exchange layout or arithmetic (slice %d/%d, impl %d/%d) than rank 0", r, (int)loops[r]->slice_mode, (int)loops[0]->slice_mode,
+               loops[r]->impl_req, loops[0]->impl_req);
     }
     return run_loops(loops, n, k_out);
 }
@@ -2029,6 +2054,22 @@ extern "C" int gnn_graph_update_labels_group(gnn_graph **dsts, gnn_graph *const 
     return GNN_OK;
 }
 
+extern "C" int gnn_lgnn_run(gnn_loop *const *loops, gnn_graph *const *graphs, int n_layers, int get_state, int get_output, float *k_out)
+{
+    ARGCHK(loops && graphs && n_layers >= 1 && k_out, "bad arguments");
+    for (int i = 0; i < n_layers; ++i) {
+        ARGCHK(loops[i] && graphs[i] && loops[i]->g == graphs[i], "loops[%d] was not created on graphs[%d]", i, i);
+        ARGCHK(i == 0 || graphs[i]->sh == graphs[0]->sh, "graphs[%d] is not derived from graphs[0]", i);
+    }
+    ARGCHK(graphs[0]->NL == graphs[0]->base_NL && !graphs[0]->arc_labels_own, "graphs[0] must be the original (underived) graph (LGNN.py:287)");
+    for (int i = 0; i < n_layers; ++i) {
+        int rc = gnn_loop_run(loops[i], 0, &k_out[i]);
+        if (rc) return rc;
+        if (i + 1 < n_layers && (rc = gnn_graph_update_labels(graphs[i + 1], graphs[0], loops[i], get_state, get_output))) return rc;
+    }
+    return GNN_OK;
+}
+
 extern "C" int gnn_loop_destroy(gnn_loop *l)
 {
     if (!l) return GNN_OK;
@@ -2046,6 +2087,8 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     (void)hipFree(l->sl_send); (void)hipFree(l->sl_state); (void)hipFree(l->sl_agg); (void)hipFree(l->sl_recv); (void)hipFree(l->agg_own);
     (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out); (void)hipFree(l->ng_part);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
+    gnn_comm *comm = l->comm;
     delete l;
+    if (comm && --comm->loops == 0 && comm->closed) return gnn_comm_destroy(comm);
     return GNN_OK;
 }

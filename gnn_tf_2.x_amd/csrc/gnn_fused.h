@@ -6,6 +6,7 @@
 constexpr int GNN_FUSED_MAXL = 3;
 constexpr int GNN_FUSED_WAVES = 8;                 // waves per (persistent) workgroup; w and w + 4 share a SIMD
 constexpr int GNN_FUSED_THREADS = 64 * GNN_FUSED_WAVES;
+constexpr int GNN_FUSED16_WAVES = 12;              // 16-node-tile kernel (gnn_fused16_kernel.h): 3 waves per SIMD
 
 struct GnnFusedArgs {
     // graph
@@ -46,6 +47,7 @@ struct GnnFusedArgs {
     // feature-sliced exchange: aggregated states of the owned rows [n_rows, Ds], computed outside the kernel (no gather), else nullptr
     const float *agg_in;
     int threads;             // threads per workgroup of the launch (0: GNN_FUSED_THREADS)
+    int single_ticket;       // 1: the launch has no more tiles than waves - a wave draws ONE ticket at start (no look-ahead tile)
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;
 };
@@ -78,5 +80,8 @@ bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsign
 bool gnn_fused_launch_s1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_s2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_s3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+// 16-node-tile kernel (split arithmetic, state width 64), 2 / 3 layers; nf: 16-feature tiles of the hidden layers (4 or 8)
+bool gnn_fused_launch_h2(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_h3(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

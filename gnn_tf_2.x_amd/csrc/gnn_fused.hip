@@ -28,10 +28,14 @@ struct FusedPlan {
     // split arithmetic (impl 2): K = 16 chunks per layer and the dword offsets of the bf16-piece images
     int chunks[MAXL] = {0, 0, 0};
     size_t s_off[MAXL] = {0, 0, 0}, s_total = 0;
+    // 16-node-tile kernel (gnn_fused16_kernel.h): K = 32 chunks, 16-feature output tiles; dword offsets of its bf16-piece image
+    int chunks16[MAXL] = {0, 0, 0}, nf16[MAXL] = {0, 0, 0};
+    size_t s16_off[MAXL] = {0, 0, 0}, s16_total = 0;
 };
 
 constexpr int GNN_FUSED_VARIANT_DEFAULT = 1;      // bit 0: raised wave priority during the gather (measured: -1 %)
 constexpr int GNN_FUSED_SPREAD_DEFAULT = 20;      // start-up spread: every wave waits 0 .. 20 x 8k cycles before its first tile (-3 %)
+constexpr int GNN_FUSED_SPREAD_SMALL_DEFAULT = 12;   // the same spread for grids with one to four tiles per wave
 constexpr int S_SLACK = 2;      // zero chunks after the layer-0 block of the split image (layer0_split looks two chunks ahead)
 
 int round_tiles(int width) { return width <= 32 ? 1 : (width <= 64 ? 2 : 4); }
@@ -81,8 +85,19 @@ bool make_plan(const gnn_mlp *m, int nlc, FusedPlan &p)
         soff += (size_t)(p.chunks[l] + (l == 0 ? S_SLACK : 0)) * p.nt[l] * 3 * 256;
     }
     p.s_total = soff;
+    soff = 0;
+    for (int l = 0; l < p.layers; ++l) {
+        p.nf16[l] = 2 * p.nt[l];
+        p.chunks16[l] = l == 0 ? 5 : p.NT;           // layer 0: always GNN_F16_CH0 = 5 chunks (K = 160, zero beyond the concat); hidden: 32 NT input features
+        p.s16_off[l] = soff;
+        soff += (size_t)p.chunks16[l] * p.nf16[l] * 3 * 256;
+    }
+    p.s16_total = soff;
     return true;
 }
+
+// the 16-node-tile kernel covers the tuned shape only: state width 64, two or three layers, hidden width 64 or 128, split arithmetic
+bool tile16_covers(const FusedPlan &p, int ds) { return ds == 64 && p.NTL == 2 && p.layers >= 2 && (p.NT == 2 || p.NT == 4); }
 
 // GNN_FUSED_WAVES wave tiles [32][KP], 128 B of slack (the layer-0 pipeline reads two groups past the last tile), GNN_FUSED_WAVES x 36 row pointers
 size_t lds_bytes(const FusedPlan &p)
@@ -104,6 +119,12 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
     const int lab = m->dims.back() + nlc;      // [state | nodes] columns in front of the alignment hole
     std::vector<float> img(p.total, 0.0f);
     std::vector<uint32_t> simg(p.s_total, 0u);
+#ifdef GNN_DIAG      // the 16-node-tile kernel (experiments/gnn_fused16_kernel.h: measured slower at every size, round 3) only exists in the diagnostic build
+    const bool want16 = tile16_covers(p, m->dims.back());
+#else
+    const bool want16 = false;
+#endif
+    std::vector<uint32_t> simg16(want16 ? p.s16_total : 0, 0u);
     std::vector<float> W, b;
     for (int l = 0; l < m->n_layers; ++l) {
         const int n_in = m->dims[l], n_out = m->dims[l + 1];
@@ -151,6 +172,33 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
                             d |= (i & 1) ? hi : (hi >> 16);
                         }
                     }
+        // image of the 16-node-tile kernel: [K = 32 chunk][16-feature out tile][piece][lane][8 bf16]; lane = (row f & 15, k group g),
+        // element i of the lane is k slot (g, i) of gnn_fused16_kernel.h; same folding factors
+        if (want16) {
+            uint32_t *sp16 = simg16.data() + p.s16_off[l];
+            const int nf = p.nf16[l];
+            for (int c = 0; c < p.chunks16[l]; ++c)
+                for (int ft = 0; ft < nf; ++ft)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int g = lane >> 4;
+                            int k = l == 0 ? 32 * c + 8 * g + i : 32 * c + 16 * (i >> 2) + 4 * g + (i & 3);
+                            if (l == 0 && p.pad) k = k < lab ? k : (k < lab + p.pad ? n_in : k - p.pad);       // LDS column -> concat column (hole: zero)
+                            const int j = 16 * ft + (lane & 15);
+                            float v = (k < n_in && j < n_out) ? W[(size_t)k * n_out + j] : 0.0f;
+                            v *= fold;
+                            for (int pc = 0; pc < 3; ++pc) {
+                                uint32_t bits;
+                                memcpy(&bits, &v, 4);
+                                const uint32_t hi = bits & 0xffff0000u;
+                                float piece;
+                                memcpy(&piece, &hi, 4);
+                                v = v - piece;
+                                uint32_t &d = sp16[((((size_t)c * nf + ft) * 3 + pc) * 64 + lane) * 4 + i / 2];
+                                d |= (i & 1) ? hi : (hi >> 16);
+                            }
+                        }
+        }
     }
     if (m->has_bn) {
         const int f = m->dims.back();
@@ -170,6 +218,14 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
         m->packed_split_dwords = p.s_total;
     }
     HIPCHK(hipMemcpy(m->packed_split, simg.data(), p.s_total * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (m->packed_split16_dwords != simg16.size()) {
+        if (m->packed_split16) (void)hipFree(m->packed_split16);
+        m->packed_split16 = nullptr;
+        m->packed_split16_dwords = 0;
+        if (!simg16.empty()) HIPCHK(hipMalloc((void **)&m->packed_split16, simg16.size() * sizeof(uint32_t)));
+        m->packed_split16_dwords = simg16.size();
+    }
+    if (!simg16.empty()) HIPCHK(hipMemcpy(m->packed_split16, simg16.data(), simg16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return GNN_OK;
 }
 
@@ -177,10 +233,13 @@ void gnn_fused_release(gnn_mlp *m)
 {
     if (m->packed) (void)hipFree(m->packed);
     if (m->packed_split) (void)hipFree(m->packed_split);
+    if (m->packed_split16) (void)hipFree(m->packed_split16);
     m->packed = nullptr;
     m->packed_split = nullptr;
+    m->packed_split16 = nullptr;
     m->packed_floats = 0;
     m->packed_split_dwords = 0;
+    m->packed_split16_dwords = 0;
 }
 
 bool gnn_fused_supported(const gnn_loop *l)
@@ -226,6 +285,8 @@ int gnn_fused_prepare(gnn_loop *l)
     }
     return GNN_OK;
 }
+
+static inline bool m_has16(const gnn_mlp *m) { return m->packed_split16 != nullptr; }
 
 // everything of the kernel arguments that does not depend on the launch geometry; split: arithmetic mode / tile layout
 static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs &a)
@@ -316,7 +377,19 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : GNN_FUSED_SPREAD_DEFAULT;   // tuning experiments
     stagger_rounds = stagger_env;
 #endif
-    a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_rounds : 0;   // only when every wave has several tiles to run
+    // start-up spread (k_fused): the full amount when every wave has four or more tiles; 12 rounds between one and four tiles per wave
+    // (round 3, tools/bench_midsize.py: N = 125 k 0.154 -> 0.138 ms, 250 k 0.227 -> 0.206 ms per iteration); none when no wave has a second tile
+    a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_rounds : (n_tiles > (size_t)GNN_FUSED_WAVES * grid ? GNN_FUSED_SPREAD_SMALL_DEFAULT : 0);
+#ifdef GNN_DIAG      // experiment: small grids (1 - 4 tiles per wave) with the two-cluster offset (variant bit 2): waves 4-7 start GNN_FUSED_STAGGER_SMALL x 8k cycles late
+    static const int stagger_small = getenv("GNN_FUSED_STAGGER_SMALL") ? atoi(getenv("GNN_FUSED_STAGGER_SMALL")) : 0;
+    const bool small_grid = n_tiles > (size_t)GNN_FUSED_WAVES * grid && n_tiles < (size_t)4 * GNN_FUSED_WAVES * grid;
+    if (small_grid && stagger_small > 0) { a.stagger = stagger_small; a.variant |= 4; }
+    static const int spread_small = getenv("GNN_FUSED_SPREAD_SMALL") ? atoi(getenv("GNN_FUSED_SPREAD_SMALL")) : -1;      // ... or the hashed spread 0 .. n rounds
+    if (small_grid && spread_small >= 0) a.stagger = spread_small;
+#endif
+    // fewer tiles than waves: a wave that drew two tickets at start would run two tiles one after the other while another wave of the
+    // launch gets none (N = 31k: 488 of 2,048 waves did all the work) - the look-ahead ticket is only drawn when every wave has a tile
+    a.single_ticket = n_tiles <= (size_t)GNN_FUSED_WAVES * grid ? 1 : 0;
     const size_t lds = lds_bytes(p);
     auto go = [&](const GnnFusedArgs &aa, unsigned gr) -> bool {
         if (split) {
@@ -330,6 +403,29 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     };
     bool ok = false;
     const int64_t n_tiles64 = (g->n_rows + 31) / 32;
+    // Experiment of round 3 (diagnostic build, GNN_FUSED_TILE16=1): 16-node tiles on v_mfma_f32_16x16x32_bf16, three waves per SIMD
+    // (experiments/gnn_fused16_kernel.h).  Correct, and slower than this kernel at every size from 31 k to 500 k nodes:
+    // every wave streams the weight image per 16 instead of 32 nodes and the vector L1 fill rate (64 B / clk / CU) becomes the bound.
+    int use16 = 0;
+#ifdef GNN_DIAG
+    static const int tile16_env = getenv("GNN_FUSED_TILE16") ? atoi(getenv("GNN_FUSED_TILE16")) : 0;
+    use16 = tile16_env && split && !a.agg_in && m_has16(l->st) && tile16_covers(p, l->Ds);
+#endif
+#ifdef GNN_DIAG
+    if (use16) {
+        GnnFusedArgs h = a;
+        const gnn_mlp *m = l->st;
+        h.Ws_base = m->packed_split16;
+        h.ws_bytes = (int)(p.s16_total * sizeof(uint32_t));
+        for (int i = 0; i < p.layers; ++i) h.ws_off[i] = (int)(p.s16_off[i] * sizeof(uint32_t));
+        h.chunks0 = p.chunks16[0];
+        const int64_t n_tiles16 = (g->n_rows + 15) / 16;
+        const unsigned grid16 = (unsigned)std::min<int64_t>((int64_t)n_cu, (n_tiles16 + GNN_FUSED16_WAVES - 1) / GNN_FUSED16_WAVES);
+        h.stagger = 0;
+        const size_t lds16 = (size_t)GNN_FUSED16_WAVES * 16 * h.KP * sizeof(float) + 128 + GNN_FUSED16_WAVES * 20 * sizeof(int) + (192 + 2 * 128) * sizeof(float) + 16;
+        ok = p.layers == 2 ? gnn_fused_launch_h2(p.act, p.nf16[0], h, grid16, lds16, l->stream) : gnn_fused_launch_h3(p.act, p.nf16[0], h, grid16, lds16, l->stream);
+    } else
+#endif
     if (l->Ds == 64 && p.NTL == 2 && n_tiles64 >= 1) {
         // the full-tile specialisation (no generic paths compiled in) on every tile; a partial last tile takes a wave-uniform
         // branch with masked row stores / condition votes (the row buffers are padded to whole tiles, rows past n_rows have no arcs)

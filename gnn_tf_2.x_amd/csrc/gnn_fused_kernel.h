@@ -359,7 +359,9 @@ struct WStream {
     __device__ __forceinline__ WStream(int start) : soff(start), n(0) {}
     __device__ __forceinline__ v4i next(__amdgpu_buffer_rsrc_t r, int voff)
     {
-        if (n == 4) { asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(soff)); n = 0; }
+        // (s_add_u32 writes SCC: without the clobber the compiler kept a loop's s_cmp result live across this statement and the loop of
+        // layer0_split16 ran once - found in round 3; the 32-node layers happened to have no SCC value live here)
+        if (n == 4) { asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(soff) : : "scc"); n = 0; }
         return bload4i(r, voff + 1024 * n++, soff);
     }
 };
@@ -1183,7 +1185,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // of the previous tile's dense layers), early enough to have that tile's row pointers and first gather ids requested.
     // (Serving the tickets heaviest-tile-first was measured: 1 % slower on the BASELINE graph.)
     int tile = 0, next_tile = 0;
-    if (lane == 0) { tile = atomicAdd(a.tile_ctr, 1); next_tile = atomicAdd(a.tile_ctr, 1); }
+    if (lane == 0) { tile = atomicAdd(a.tile_ctr, 1); next_tile = a.single_ticket ? 0x3fffffff : atomicAdd(a.tile_ctr, 1); }
     tile = __builtin_amdgcn_readfirstlane(tile) + a.tile_base;
     next_tile = __builtin_amdgcn_readfirstlane(next_tile) + a.tile_base;
     int ip_cur = tile_rowptr_clamp(a, tile, lane, tile_rowptr_request(a, tile, lane));

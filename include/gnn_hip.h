@@ -228,6 +228,21 @@ int gnn_loop_set_profiling(gnn_loop *l, int enable);
  * drops them, so that the next gnn_loop_run pays for them like every Loop() of the reference does (bench.py: cold figure). */
 int gnn_loop_drop_cached_aggregates(gnn_loop *l);
 int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *avg_iter_ms, int *n_iter_timed);
+/* Work counters of one iteration of this loop on this rank and the timing of its last run (SURVEY.md 8b "gnn_counters_get"):
+ * algorithmic bytes per iteration = E (4 Ds + 8) + 4 (n_rows + 1) + n_rows (8 Ds + 4 (2 NL + AL)) over the OWNED rows (SURVEY.md
+ * 8d: fp32 values, int32 indices, no cache credit, fused iteration), FLOPs per iteration = n_rows 2 sum_l in_l out_l + 2 E Ds;
+ * iterations / total_ms / avg_iteration_ms as gnn_loop_get_timing (the times are 0 unless gnn_loop_set_profiling was on).
+ * Any output pointer may be NULL. */
+int gnn_counters_get(const gnn_loop *l, double *bytes_per_iteration, double *flops_per_iteration, int *iterations, float *total_ms,
+                     float *avg_iteration_ms);
+/* LGNN.Loop (reference GNN/LGNN.py:263-290) in one call: loops[i] was created on graphs[i]; graphs[0] is the ORIGINAL graph `base`,
+ * graphs[i > 0] derived from it (gnn_graph_derive / _derive_edge; the same derived graph may serve several layers).  Runs layer 0,
+ * relabels graphs[1] from `base` with layer 0's state / output (gnn_graph_update_labels: LGNN.py:227-260, :287), runs layer 1, ...
+ * k_out[n_layers] receives the iteration count of every layer (K of the reference); state / outputs of every layer stay readable
+ * through gnn_loop_get_state / gnn_loop_get_output (or gnn_loop_readout) of its loop.  Single GPU or one rank of an RCCL job. */
+int gnn_lgnn_run(gnn_loop *const *loops, gnn_graph *const *graphs, int n_layers, int get_state, int get_output, float *k_out);
+/* A loop created on a communicator may be destroyed before or after it: gnn_comm_destroy with loops alive only marks the
+ * communicator closed, the last gnn_loop_destroy releases it. */
 int gnn_loop_destroy(gnn_loop *l);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) -------------------------------------------------------------

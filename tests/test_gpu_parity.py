@@ -629,3 +629,58 @@ def test_persistent_small_graph_loop(d, nl, al, hidden, act, n):
             loop.close()
     big = e.Loop(_device_graph(_case(rng, n=8193, d=4)[0]), *[e.Mlp(x['weights'], x['activations'], True) for x in _case(np.random.default_rng(1), n=8193, d=4)[1:3]], 4, 5, 0.01)
     assert not big.set_persistent(True)                   # 257 tiles: not all resident at once by the conservative rule
+
+
+def test_lgnn_run_in_one_call_and_work_counters():
+    """gnn_lgnn_run = LGNN.Loop (reference LGNN.py:263-290) of a whole stack through ONE C-ABI call: layer i on graphs[i], relabelling
+    from the ORIGINAL graph in between; bit-identical to the C oracle chain.  gnn_counters_get: the algorithmic work of one iteration."""
+    e = _engine()
+    rng = np.random.default_rng(16)
+    n, d, layers = 900, 8, 3
+    arcs = random_arcs(rng, n, 3 * n, 1)
+    nodes = (2 * rng.random((n, 3)) - 1).astype(np.float32)
+    gd = orc.make_graph_dict(arcs, nodes, 'average')
+    base = _device_graph(gd)
+    derived = base.derive(2)                      # get_state=False, get_output=True: NL' = 3 + 2; one derived graph serves layers 1..
+    nets, loops, s0s = [], [], []
+    for layer in range(layers):
+        ins, ls = orc.get_inout_dims('state', 3, 1, 2, 'n', d, [16], layer=layer, get_state=False, get_output=True)
+        ino, lo = orc.get_inout_dims('output', 3, 1, 2, 'n', d, None, layer=layer, get_state=False, get_output=True)
+        st, ou = make_mlp(rng, ins, ls, 'selu', gain=0.5), make_mlp(rng, ino, lo, 'softmax')
+        nets.append((st, ou))
+        lp = e.Loop(base if layer == 0 else derived, e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), d, 12, 0.01)
+        lp.set_impl(1)
+        s0s.append((0.1 * rng.standard_normal((n, d))).astype(np.float32))
+        lp.set_state0(s0s[-1])
+        loops.append(lp)
+    K = e.Loop.lgnn_run(loops, [base] + [derived] * (layers - 1), False, True)
+    gtmp, Kc = dict(gd), []
+    for (st, ou), s0, lp in zip(nets, s0s, loops):
+        kc, sc, oc = corc.loop_node(gtmp, st, ou, d, 12, 0.01, s0)
+        Kc.append(kc)
+        assert np.array_equal(lp.output(), oc)
+        gtmp = orc.update_graph(gd, sc, oc, False, True)
+    assert K == Kc and np.array_equal(loops[-1].state(), sc)
+    with pytest.raises(ValueError):                # loops[1] does not belong to graphs[1] = base
+        e.Loop.lgnn_run(loops, [base] * layers, False, True)
+    c = loops[0].counters()
+    E, nl, al = len(arcs), 3, 1
+    assert c['bytes_per_iteration'] == E * (4 * d + 8) + 4 * (n + 1) + n * (8 * d + 4 * (2 * nl + al))          # SURVEY.md 8d
+    assert c['flops_per_iteration'] == n * 2 * ((al + 2 * (nl + d)) * 16 + 16 * d) + 2 * E * d and c['iterations'] == int(K[0])
+    for lp in loops: lp.close()
+    derived.close(); base.close()
+
+
+def test_communicator_may_be_destroyed_before_its_loops():
+    """gnn_comm_destroy with loops alive only marks the communicator closed; the last gnn_loop_destroy releases it."""
+    e = _engine()
+    rng = np.random.default_rng(3)
+    g, st, ou, s0 = _case(rng, n=200, d=8)
+    comm = e.Comm(e.Comm.unique_id(), 0, 1, 0)
+    loop = e.Loop(_device_graph(g), e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 8, 10, 0.01, comm)
+    loop.set_state0(s0)
+    comm.close()                                   # before the loop: must stay usable
+    k = loop.run()
+    kc, sc, oc = corc.loop_node(g, st, ou, 8, 10, 0.01, s0)
+    assert k == kc and np.array_equal(loop.state(), sc)
+    loop.close()

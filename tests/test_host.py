@@ -273,3 +273,21 @@ def test_save_load_round_trip(tmp_path):
     assert lb.LAYERS == 2 and (lb.get_state, lb.get_output) == (False, True) and isinstance(lb.gnns[0], GNNgraphBased)
     for g0, g1 in zip(lg.gnns, lb.gnns):
         assert all(np.array_equal(x, y) for x, y in zip(g0.net_state.get_weights(), g1.net_state.get_weights()))
+
+
+def test_optimizer_counts_a_device_step_only_after_it_succeeded_and_restarts_on_a_path_switch():
+    from GNN import optimizers
+    opt = optimizers.Adam(learning_rate=0.01)
+    kind, hyper = opt.device_step_args()
+    assert kind == 1 and opt.iterations == 0                    # asking for the arguments does not count the step
+    kind2, hyper2 = opt.device_step_args()
+    assert hyper2 == hyper                                      # ... so a failed step is retried with the same bias correction
+    opt.device_step_done()
+    assert opt.iterations == 1 and opt.device_step_args()[1][0] != hyper[0]
+    token = opt._slot_token
+    # the same optimizer now drives a host-side update: slots and counter restart together (a fresh Keras optimizer)
+    p = np.ones(3, np.float32)
+    new = opt.apply_gradients([(np.ones(3, np.float32), p)])
+    assert opt.iterations == 1 and opt._slot_token is not token and np.allclose(new[0], p - 0.01, atol=1e-6)
+    opt.device_step_args()                                      # and back: again from zero
+    assert opt.iterations == 0 and opt._m is None
