@@ -15,12 +15,14 @@
 // reduction over rows leaves per-chunk partials that are added in a fixed order (no float atomics, run-to-run identical), so
 // results are compared with the float64 oracle to a tolerance, not bit for bit.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <vector>
 
 #include "gnn_common.h"
+#include "gnn_fused_kernel.h"     // layer_from_lds / f32x16: the f32-MFMA K-step pipeline of the exact fused path, reused by the wide dense products
 
 namespace {
 
@@ -513,6 +515,571 @@ __global__ void __launch_bounds__(256) k_layer_bwd(const LayerBwd p)
         dense_bwd_block<R>((int64_t)blockIdx.x - p.wg_blocks, p.n, p.n_out, p.n_out_pad, p.n_in, p.cshift, p.DZ, p.WT, p.keep, p.rate, p.a_prev, p.act, p.dprev, lds);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide layers (round 3): the three dense products of a Dense layer on the matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32
+// accumulate, every product exact, the k-ordered fmaf chain of the per-op kernels - so results do not depend on the grid).
+//   forward      a      = act(h . W + b)                        k_gemm_f32, weights as the A operand, 32 rows of h per wave as B
+//   backward     d h_in = d z . W^T (x Dropout / act' epilogue)   k_gemm_f32 on W^T
+//                [dW; db] = [h | 1]^T . d z                      k_wgrad_f32: rows are the K dimension; per-chunk partials, added in
+//                                                               chunk order afterwards like every other reduction of the step
+// BASELINE configs[2] shape (1 M rows, 135 -> 128 -> 128 -> 64): k_dense_fwd 1.08 ms and k_layer_bwd 2.02 ms per layer on the FP32
+// ALUs before (profiles/r03_train_c3.txt).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int TG_WAVES = 8;
+constexpr int64_t GNN_TRAIN_MFMA_MIN_ROWS = 4096;      // below that a step is launch-bound (MUTAG batches: 570 rows) and the per-op kernels are as fast
+
+// packed A operand of layer_from_lds for output columns [col0, col0 + 32 NO) of M [K, n_cols]: wp[(kk 64 + lane) NO + j] =
+// M[2 kk + (lane >> 5)][col0 + 32 j + (lane & 31)], zero outside the matrix (K-steps up to kk_total: the pipeline's look-ahead)
+__global__ void k_pack_exact(int K, int n_cols, int col0, int NO, int kk_total, const float *__restrict__ M, float *__restrict__ wp)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= kk_total * 64 * NO) return;
+    const int j = t % NO, lane = (t / NO) & 63, kk = t / (64 * NO);
+    const int k = 2 * kk + (lane >> 5), c = col0 + 32 * j + (lane & 31);
+    wp[t] = (k < K && c < n_cols) ? M[(size_t)k * n_cols + c] : 0.0f;
+}
+
+struct GemmArgs {
+    int64_t n;
+    int K, KP, kk, n_cols, col0, act, mode, spread;       // mode 0: forward (bias + activation); 1: backward (Dropout / act' of the producer)
+    float rate;
+    const float *X, *wp, *bias, *a_prev;
+    const uint8_t *keep;
+    float *Y;
+};
+
+// Y[r, col0 .. col0 + 32 NO) = epilogue(X[r, :] . M[:, col0 ..]) for all rows; X dense [n, K], Y dense [n, n_cols].
+// One wave = 32 rows: rows staged in LDS (odd row stride: conflict-free column reads), K-steps through layer_from_lds.  All pieces of a
+// tile (up to 18 x 16 B per lane) are requested before the first is written to LDS: one round trip per tile, covered by the SIMD's other
+// wave.  (Measured, profiles/r03_train_c3.txt: a staging loop with a load per iteration - 17 dependent round trips - 0.89 ms per
+// 1 M x 135 x 128 product; the NEXT tile's rows held in registers across the K-steps: 256 VGPRs + 163 spilled, 1.06 ms.)
+constexpr int TG_MAXQ = 18;                        // 16-byte pieces per lane of a 32 x 144 tile
+
+template <int ACT, int NO>
+__device__ __forceinline__ void gemm_store_fwd(const GemmArgs &p, f32x16 (&acc)[NO], int64_t row, int half, bool vec)
+{
+    using namespace gnn_fused_dev;
+#pragma unroll
+    for (int jt = 0; jt < NO; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int f0 = p.col0 + 32 * jt + 8 * q + 4 * half;
+            const int64_t o = row * p.n_cols + f0;
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = f0 + u < p.n_cols ? act_t<ACT>(acc[jt][4 * q + u] + p.bias[f0 + u]) : 0.0f;
+            if (vec && f0 + 4 <= p.n_cols) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(p.Y) + o) = v4f{v[0], v[1], v[2], v[3]};
+            else
+                for (int u = 0; u < 4; ++u) if (f0 + u < p.n_cols) gptr_w(p.Y)[o + u] = v[u];
+        }
+}
+
+template <int NO>
+__global__ void __launch_bounds__(64 * TG_WAVES, 2) k_gemm_f32(const GemmArgs p)
+{
+    using namespace gnn_fused_dev;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = p.K, KP = p.KP;
+    float *X = lds + (size_t)wave * 32 * KP;
+    for (int t = lane; t < 32 * (KP - K); t += 64) X[(t / (KP - K)) * KP + K + t % (KP - K)] = 0.0f;      // columns >= K: zero, once
+    const int64_t n_tiles = (p.n + 31) / 32;
+    const float inv_k = 1.0f / (float)K;
+    const int half = lane >> 5, node = lane & 31;
+    const int64_t stride = (int64_t)gridDim.x * TG_WAVES;
+    const bool vec = (p.n_cols & 3) == 0;
+    v4f nxt[TG_MAXQ];
+    auto request = [&](int64_t tile) {                                   // rows of `tile` -> registers (zeros past the matrix)
+        const int64_t i0 = tile * 32;
+        const int total = tile < n_tiles ? (int)((p.n - i0) < 32 ? (p.n - i0) : 32) * K : 0;
+        const float *src = p.X + i0 * K;
+#pragma unroll
+        for (int q = 0; q < TG_MAXQ; ++q) {
+            const int e = lane * 4 + 256 * q;
+            nxt[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (e + 4 <= total) nxt[q] = gload4(src + e);
+            else if (e < total) {                                        // tail of a partial last tile
+                float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 4; ++u) if (e + u < total) t4[u] = gload1(src + e + u);
+                nxt[q] = v4f{t4[0], t4[1], t4[2], t4[3]};
+            }
+        }
+    };
+    for (int64_t tile = (int64_t)blockIdx.x * TG_WAVES + wave; tile < n_tiles; tile += stride) {
+        const int64_t i0 = tile * 32;
+        const int nvalid = (int)((p.n - i0) < 32 ? (p.n - i0) : 32);
+        request(tile);
+        int lane_o = lane;                      // opaque per tile: the 72 (row, column) pairs below are loop-invariant and would otherwise be
+        asm volatile("" : "+v"(lane_o));        // hoisted out of the tile loop and kept in registers across the K-steps (163 spills)
+#pragma unroll
+        for (int q = 0; q < TG_MAXQ; ++q) {
+            const int e = lane_o * 4 + 256 * q;
+            if (e < 32 * K) {
+                const float v[4] = {nxt[q].x, nxt[q].y, nxt[q].z, nxt[q].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ee = e + u, r = (int)(((float)ee + 0.5f) * inv_k), c = ee - r * K;
+                    X[r * KP + c] = v[u];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        f32x16 acc[NO];
+        zero_acc<NO>(acc);
+        layer_from_lds<NO>(X + node * KP + half, p.wp + (size_t)lane * NO, p.kk, acc, 1);
+        int half_o = half;                      // (opaque per tile as well: the 64 bias values / output offsets of the epilogue are loop-invariant too)
+        asm volatile("" : "+v"(half_o));
+        if (node < nvalid) {
+            const int64_t row = i0 + node;
+            const int half = half_o;
+            if (p.mode == 0) {
+                switch (p.act) {
+                case GNN_ACT_RELU: gemm_store_fwd<GNN_ACT_RELU, NO>(p, acc, row, half, vec); break;
+                case GNN_ACT_SELU: gemm_store_fwd<GNN_ACT_SELU, NO>(p, acc, row, half, vec); break;
+                case GNN_ACT_ELU: gemm_store_fwd<GNN_ACT_ELU, NO>(p, acc, row, half, vec); break;
+                case GNN_ACT_TANH: gemm_store_fwd<GNN_ACT_TANH, NO>(p, acc, row, half, vec); break;
+                case GNN_ACT_SIGMOID: gemm_store_fwd<GNN_ACT_SIGMOID, NO>(p, acc, row, half, vec); break;
+                default: gemm_store_fwd<GNN_ACT_LINEAR, NO>(p, acc, row, half, vec); break;       // (softmax is applied by the caller)
+                }
+            } else {
+#pragma unroll
+                for (int jt = 0; jt < NO; ++jt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = p.col0 + 32 * jt + 8 * q + 4 * half;
+                        const int64_t o = row * p.n_cols + f0;
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            float x = acc[jt][4 * q + u];
+                            if (f0 + u < p.n_cols) {
+                                if (p.keep) x = dropout_grad(x, p.keep[o + u], p.rate);
+                                if (p.act >= 0) x = x * act_grad(p.a_prev[o + u], p.act);
+                            }
+                            v[u] = x;
+                        }
+                        if (vec && f0 + 4 <= p.n_cols) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(p.Y) + o) = v4f{v[0], v[1], v[2], v[3]};
+                        else
+                            for (int u = 0; u < 4; ++u) if (f0 + u < p.n_cols) gptr_w(p.Y)[o + u] = v[u];
+                    }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the next tile re-uses this wave's LDS region
+    }
+}
+
+// The same product in the split arithmetic of the fused inference kernel (gnn_fused_kernel.h: every fp32 operand cut into three exact
+// bf16 pieces, six piece products per term on v_mfma_f32_32x32x16_bf16, fp32 accumulation): 2.7 x fewer matrix-pipe cycles than the f32
+// MFMA, and the bf16 MFMA overlaps the wave's VALU work.  Packed operand: [K = 16 chunk][out tile][piece][lane][8 bf16] + two zero chunks.
+__global__ void k_pack_split(int K, int n_cols, int col0, int NO, int chunks_img, const float *__restrict__ M, uint32_t *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;                 // one thread per (chunk, tile, lane, element pair): three dwords (pieces)
+    if (t >= chunks_img * NO * 64 * 4) return;
+    const int j2 = t & 3, lane = (t >> 2) & 63, jt = (t >> 8) % NO, c = (t >> 8) / NO;
+    uint32_t d[3] = {0u, 0u, 0u};
+    for (int e = 0; e < 2; ++e) {
+        const int i = 2 * j2 + e, k = 16 * c + 8 * (lane >> 5) + i, col = col0 + 32 * jt + (lane & 31);
+        float v = (k < K && col < n_cols) ? M[(size_t)k * n_cols + col] : 0.0f;
+        for (int pc = 0; pc < 3; ++pc) {                                 // truncation split: v == p0 + p1 + p2 exactly
+            const uint32_t hi = __float_as_uint(v) & 0xffff0000u;
+            v = v - __uint_as_float(hi);
+            d[pc] |= e ? hi : (hi >> 16);
+        }
+    }
+    for (int pc = 0; pc < 3; ++pc) out[((((size_t)c * NO + jt) * 3 + pc) * 64 + lane) * 4 + j2] = d[pc];
+}
+
+template <int NO>
+__global__ void __launch_bounds__(64 * TG_WAVES, 2) k_gemm_split(const GemmArgs p)
+{
+    using namespace gnn_fused_dev;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = p.K, KP = p.KP;                                        // KP: a multiple of 4 with KP / 4 odd (16-byte rows, conflict-free b128 column reads)
+    float *X = lds + (size_t)wave * 32 * KP;
+    float *bias_lds = lds + (size_t)TG_WAVES * 32 * KP + 32;             // [32 NO]: the accumulators start from it (zeros in backward mode)
+    for (int t = threadIdx.x; t < 32 * NO; t += blockDim.x) bias_lds[t] = (p.mode == 0 && p.col0 + t < p.n_cols) ? p.bias[p.col0 + t] : 0.0f;
+    for (int t = lane; t < 32 * (KP - K); t += 64) X[(t / (KP - K)) * KP + K + t % (KP - K)] = 0.0f;      // columns >= K: zero, once
+    __syncthreads();
+    const int64_t n_tiles = (p.n + 31) / 32;
+    const float inv_k = 1.0f / (float)K;
+    const int half = lane >> 5, node = lane & 31;
+    const int64_t stride = (int64_t)gridDim.x * TG_WAVES;
+    const bool vec = (p.n_cols & 3) == 0, kvec = (K & 3) == 0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wp), 0, p.kk, 0x00020000);      // (kk: bytes of the packed image here)
+    // start-up spread (as k_fused): all waves run the same phases - load, K-steps, store - on tiles of equal cost; started together they
+    // would load together and compute together.  Every wave waits a different fraction of about one tile period first.
+    if (n_tiles >= 4 * stride) {
+        const int rounds = (int)((((unsigned)blockIdx.x * TG_WAVES + (unsigned)wave) * 0x9E3779B1u) >> 16) % (unsigned)(p.spread + 1);
+        for (int i = 0; i < rounds; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    v4f nxt[TG_MAXQ];
+    for (int64_t tile = (int64_t)blockIdx.x * TG_WAVES + wave; tile < n_tiles; tile += stride) {
+        const int64_t i0 = tile * 32;
+        const int nvalid = (int)((p.n - i0) < 32 ? (p.n - i0) : 32);
+        const int total = nvalid * K;
+        const float *src = p.X + i0 * K;
+#pragma unroll
+        for (int q = 0; q < TG_MAXQ; ++q) {                              // all pieces of the tile requested before the first is used
+            const int e = lane * 4 + 256 * q;
+            nxt[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (e + 4 <= total) nxt[q] = gload4(src + e);
+            else if (e < total) {                                        // tail of a partial last tile
+                float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 4; ++u) if (e + u < total) t4[u] = gload1(src + e + u);
+                nxt[q] = v4f{t4[0], t4[1], t4[2], t4[3]};
+            }
+        }
+        int lane_o = lane;                      // opaque per tile (see k_gemm_f32)
+        asm volatile("" : "+v"(lane_o));
+        if (K < 32 * NO) {                      // the previous tile's output pass left values in columns [K, 32 NO): zero again (0 x Inf would poison the sums)
+            const int zw = 32 * NO - K;
+            for (int t = lane_o; t < 32 * zw; t += 64) X[(t / zw) * KP + K + t % zw] = 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < TG_MAXQ; ++q) {
+            const int e = lane_o * 4 + 256 * q;
+            if (e < 32 * K) {
+                if (kvec) {                                              // rows are whole 16-byte pieces
+                    const int r = (int)(((float)e + 0.5f) * inv_k), c = e - r * K;
+                    *reinterpret_cast<v4f *>(X + r * KP + c) = nxt[q];
+                } else {
+                    const float v[4] = {nxt[q].x, nxt[q].y, nxt[q].z, nxt[q].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ee = e + u, r = (int)(((float)ee + 0.5f) * inv_k), c = ee - r * K;
+                        X[r * KP + c] = v[u];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        f32x16 acc[NO];
+        layer0_split<NO, true>(X + node * KP + 8 * half, wrs, lane * 16, 0, (K + 15) / 16, acc, bias_lds, half);
+        // Epilogue in two steps, so that every global access is a whole row piece: (1) the accumulators (feature on the register, row on
+        // the lane) go to the wave's LDS tile as [row][column] (16-byte pieces, row stride KP: KP / 4 odd, conflict-free); (2) lanes take
+        // consecutive 16-byte pieces of consecutive rows - 512 contiguous bytes per 32 lanes for a 128-wide pass - read the matching
+        // pieces of the producer's activation / Dropout mask, apply bias-included activation or the derivative, and store.  (Stores of
+        // 16-byte pieces straight from the accumulator layout touch 32 rows per instruction: 0.63 ms per product whatever K.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // all B-operand reads of the tile are done: its LDS region is free
+        int half_o = half;
+        asm volatile("" : "+v"(half_o));
+#pragma unroll
+        for (int jt = 0; jt < NO; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<v4f *>(X + node * KP + 32 * jt + 8 * q + 4 * half_o) = v4f{acc[jt][4 * q], acc[jt][4 * q + 1], acc[jt][4 * q + 2], acc[jt][4 * q + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        constexpr int PPR = 8 * NO;                                      // 16-byte pieces per row of this pass
+        int lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+#pragma unroll
+        for (int u = 0; u < 32 * PPR / 64; ++u) {
+            const int idx = lane_p + 64 * u, r = idx / PPR, c = (idx % PPR) * 4;
+            const int f0 = p.col0 + c;
+            if (r < nvalid && f0 < p.n_cols) {
+                const v4f a4 = *reinterpret_cast<const v4f *>(X + r * KP + c);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                const int64_t o = (i0 + r) * p.n_cols + f0;
+                const bool full = vec && f0 + 4 <= p.n_cols;
+                if (p.mode == 0) {
+                    // hardware transcendentals (v_exp_f32 / v_rcp_f32, 1 ulp: act_fast of the fused inference path); the backward pass
+                    // differentiates from the stored activation, so forward and backward stay consistent
+                    switch (p.act) {
+                    case GNN_ACT_RELU: for (int t = 0; t < 4; ++t) v[t] = act_fast<GNN_ACT_RELU>(v[t]); break;
+                    case GNN_ACT_SELU: for (int t = 0; t < 4; ++t) v[t] = act_fast<GNN_ACT_SELU>(v[t]); break;
+                    case GNN_ACT_ELU: for (int t = 0; t < 4; ++t) v[t] = act_fast<GNN_ACT_ELU>(v[t]); break;
+                    case GNN_ACT_TANH: for (int t = 0; t < 4; ++t) v[t] = act_fast<GNN_ACT_TANH>(v[t]); break;
+                    case GNN_ACT_SIGMOID: for (int t = 0; t < 4; ++t) v[t] = act_fast<GNN_ACT_SIGMOID>(v[t]); break;
+                    default: break;
+                    }
+                } else {
+                    if (p.keep)
+                        for (int t = 0; t < 4; ++t) if (f0 + t < p.n_cols) v[t] = dropout_grad(v[t], p.keep[o + t], p.rate);
+                    if (p.act >= 0) {
+                        if (full) {
+                            const v4f ap = gload4(p.a_prev + o);
+                            v[0] *= act_grad(ap.x, p.act); v[1] *= act_grad(ap.y, p.act); v[2] *= act_grad(ap.z, p.act); v[3] *= act_grad(ap.w, p.act);
+                        } else
+                            for (int t = 0; t < 4; ++t) if (f0 + t < p.n_cols) v[t] *= act_grad(p.a_prev[o + t], p.act);
+                    }
+                }
+                if (full) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(p.Y) + o) = v4f{v[0], v[1], v[2], v[3]};
+                else
+                    for (int t = 0; t < 4; ++t) if (f0 + t < p.n_cols) gptr_w(p.Y)[o + t] = v[t];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the next tile re-uses this wave's LDS region
+    }
+}
+
+// K-steps of the wide products: a multiple of 12 (layer_from_lds consumes groups of 3 x 4) plus its look-ahead of 8
+inline int tg_kk(int K) { return ((K + 1) / 2 + 11) / 12 * 12; }
+inline int tg_kp(int K) { return std::max(2 * tg_kk(K), (K + 15) / 16 * 16) + 1; }
+inline bool tg_many_rows(int64_t n)
+{
+#ifdef GNN_DIAG      // GNN_TRAIN_MFMA=0: the round-2 kernels everywhere (accuracy / timing comparison)
+    static const bool off = getenv("GNN_TRAIN_MFMA") && atoi(getenv("GNN_TRAIN_MFMA")) == 0;
+    if (off) return false;
+#endif
+    return n >= GNN_TRAIN_MFMA_MIN_ROWS;
+}
+inline bool tg_wide(int n_in, int n_out) { return n_in >= 64 && n_out >= 32 && n_in <= 144; }      // (TG_MAXQ pieces of a 32-row tile per lane)
+
+// Y = epilogue(X . M) over all column passes of M [K, n_cols]; scratch for the packed operand comes from the step's arena
+inline int tg_kps(int K) { int kp = ((K + 15) / 16 * 16 + 3) / 4 * 4; if ((kp / 4) % 2 == 0) kp += 4; return kp; }
+
+template <class BufT>      // (Buf is defined further down with the arena)
+int launch_gemm_f32(hipStream_t st, BufT &buf, int64_t n, int K, int n_cols, const float *X, const float *M, const float *bias, int act, int mode,
+                    const uint8_t *keep, float rate, const float *a_prev, float *Y)
+{
+    static bool raised = false;
+    if (!raised) {
+        const void *ks[6] = {reinterpret_cast<const void *>(&k_gemm_f32<4>), reinterpret_cast<const void *>(&k_gemm_f32<2>), reinterpret_cast<const void *>(&k_gemm_f32<1>),
+                             reinterpret_cast<const void *>(&k_gemm_split<4>), reinterpret_cast<const void *>(&k_gemm_split<2>), reinterpret_cast<const void *>(&k_gemm_split<1>)};
+        for (const void *k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    bool split = true;                             // shipped: the split-bf16 products; the f32-MFMA form stays as the exact-chain cross-check
+#ifdef GNN_DIAG
+    static const bool f32_env = getenv("GNN_TRAIN_GEMM_F32") != nullptr;
+    split = !f32_env;
+#endif
+    GemmArgs p{};
+    p.n = n; p.K = K; p.n_cols = n_cols; p.act = act; p.mode = mode; p.rate = rate;
+    p.X = X; p.bias = bias; p.a_prev = a_prev; p.keep = keep; p.Y = Y;
+    p.spread = 0;                                  // (measured: 0 .. 8 rounds of start-up spread change nothing here, profiles/r03_train_c3.txt)
+#ifdef GNN_DIAG
+    static const int spread_env = getenv("GNN_TRAIN_SPREAD") ? atoi(getenv("GNN_TRAIN_SPREAD")) : 0;
+    p.spread = spread_env;
+#endif
+    p.KP = split ? std::max(tg_kps(K), tg_kps(std::min(128, (n_cols + 31) / 32 * 32))) : tg_kp(K);      // (split: the tile is re-used for the pass's output columns)
+    const size_t lds = sizeof(float) * ((size_t)TG_WAVES * 32 * p.KP + 32 + 128) + 16;
+    if (lds > 160 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "layer input width %d too large for the matrix-core path", K);
+    const int64_t n_tiles = (n + 31) / 32;
+    const unsigned grid = (unsigned)std::min<int64_t>(256, (n_tiles + TG_WAVES - 1) / TG_WAVES);
+    for (int col0 = 0; col0 < n_cols;) {
+        const int left = (n_cols - col0 + 31) / 32, NO = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+        int rc;
+        p.col0 = col0;
+        if (split) {
+            const int chunks_img = (K + 15) / 16 + 2;
+            uint32_t *img = nullptr;
+            if ((rc = buf.get(&img, (size_t)chunks_img * NO * 3 * 256))) return rc;
+            hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)chunks_img * NO * 256, 256), 256, 0, st, K, n_cols, col0, NO, chunks_img, M, img);
+            p.wp = reinterpret_cast<const float *>(img);
+            p.kk = (int)((size_t)chunks_img * NO * 3 * 256 * sizeof(uint32_t));      // bytes of the image (buffer descriptor)
+            if (NO == 4) hipLaunchKernelGGL((k_gemm_split<4>), grid, 64 * TG_WAVES, lds, st, p);
+            else if (NO == 2) hipLaunchKernelGGL((k_gemm_split<2>), grid, 64 * TG_WAVES, lds, st, p);
+            else hipLaunchKernelGGL((k_gemm_split<1>), grid, 64 * TG_WAVES, lds, st, p);
+        } else {
+            p.kk = tg_kk(K);
+            float *wp = nullptr;
+            const int kk_img = p.kk + 8;
+            if ((rc = buf.get(&wp, (size_t)kk_img * 64 * NO))) return rc;
+            hipLaunchKernelGGL(k_pack_exact, cdiv((int64_t)kk_img * 64 * NO, 256), 256, 0, st, K, n_cols, col0, NO, kk_img, M, wp);
+            p.wp = wp;
+            if (NO == 4) hipLaunchKernelGGL((k_gemm_f32<4>), grid, 64 * TG_WAVES, lds, st, p);
+            else if (NO == 2) hipLaunchKernelGGL((k_gemm_f32<2>), grid, 64 * TG_WAVES, lds, st, p);
+            else hipLaunchKernelGGL((k_gemm_f32<1>), grid, 64 * TG_WAVES, lds, st, p);
+        }
+        HIPCHK(hipGetLastError());
+        col0 += 32 * NO;
+    }
+    return GNN_OK;
+}
+
+// [dW; db] partials of one row chunk: D[hf, zf] = sum over the chunk's rows of [H | 1][r, hf] d z[r, zf].  Rows are the K dimension of
+// the 32x32x2 MFMA: lane (m, k half) loads H[r0 + 2 kk + k half][32 mt + m] and d z[..][32 nt + m] - whole 128-byte row pieces per
+// half-wave, straight from memory, no staging.  Block = 4 waves, each a quarter of the chunk's rows, MT tiles of [H | 1] columns x up to
+// two tiles of d z columns; the four partial tiles are added in wave order through LDS (fixed order: run-to-run identical).
+struct WgradArgs {
+    int64_t n, rows_per_block, pstride;
+    int n_in, n_out;
+    const float *H, *DZ;
+    float *part;
+};
+
+template <int MT, int NT2>
+__global__ void __launch_bounds__(256, 2) k_wgrad_f32(const WgradArgs p)
+{
+    using namespace gnn_fused_dev;
+    __shared__ float red[3][1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, kh = lane >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * p.rows_per_block, c1 = c0 + p.rows_per_block < p.n ? c0 + p.rows_per_block : p.n;
+    const int64_t quarter = ((c1 - c0 + 3) / 4 + 1) & ~(int64_t)1;                 // even: K-steps are row pairs
+    const int64_t r0 = c0 + wave * quarter, r1 = r0 + quarter < c1 ? r0 + quarter : c1;
+    const int nt0 = blockIdx.y * NT2;
+    f32x16 acc[MT][NT2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) zero_acc<NT2>(acc[a]);
+    constexpr int PF = 4;
+    float av[PF][MT], bv[PF][NT2];
+    auto load = [&](int slot, int64_t r) {
+        const int64_t rr = r + kh;
+        const bool in = rr < r1;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            const int hf = 32 * a + m;
+            av[slot][a] = in ? (hf < p.n_in ? gload1(p.H + rr * p.n_in + hf) : (hf == p.n_in ? 1.0f : 0.0f)) : 0.0f;
+        }
+#pragma unroll
+        for (int b = 0; b < NT2; ++b) {
+            const int zf = 32 * (nt0 + b) + m;
+            bv[slot][b] = (in && zf < p.n_out) ? gload1(p.DZ + rr * p.n_out + zf) : 0.0f;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) load(s, r0 + 2 * s);
+    for (int64_t r = r0; r < r1; r += 2 * PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            float a_[MT], b_[NT2];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) a_[a] = av[s][a];
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) b_[b] = bv[s][b];
+            load(s, r + 2 * (s + PF));                                               // rows past r1 load zeros
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[a], b_[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D[row hf = 32 a + (r & 3) + 8 (r >> 2) + 4 kh][col zf = 32 (nt0 + b) + m]
+    float *out = p.part + (size_t)blockIdx.x * p.pstride;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT2; ++b) {
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][r * 64 + lane] = acc[a][b][r];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int zf = 32 * (nt0 + b) + m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[a][b][r];
+                    v = v + red[0][r * 64 + lane]; v = v + red[1][r * 64 + lane]; v = v + red[2][r * 64 + lane];
+                    const int hf = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (hf <= p.n_in && zf < p.n_out) out[(size_t)hf * p.n_out + zf] = v;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+#ifdef GNN_DIAG
+// EXPERIMENT (diagnostic build, GNN_TRAIN_WGRAD_SPLIT=1; round 3): the same partials in split arithmetic (three exact bf16 pieces per
+// operand, six piece products on v_mfma_f32_32x32x16_bf16): rows are the K dimension, 16 per step - lane (m, k half) holds
+// H[r + 8 k half + i][32 a + m], i < 8, eight coalesced row pieces per operand tile, cut into pieces in registers.  60 bf16 MFMAs
+// (1,920 matrix-pipe cycles) per 16 rows instead of 80 f32 MFMAs (5,120) - and measured SLOWER: 0.92 ms against 0.42 ms per
+// 1 M x 129 x 128 gradient (256 VGPRs + 33 spilled; fifty-six dependent row-piece loads per K-step).  Correct (the training tests pass with it).
+template <int MT, int NT2>
+__global__ void __launch_bounds__(256, 2) k_wgrad_split(const WgradArgs p)
+{
+    using namespace gnn_fused_dev;
+    __shared__ float red[3][1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, kh = lane >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * p.rows_per_block, c1 = c0 + p.rows_per_block < p.n ? c0 + p.rows_per_block : p.n;
+    const int64_t quarter = ((c1 - c0 + 3) / 4 + 15) & ~(int64_t)15;                // whole K = 16 steps
+    const int64_t r0 = c0 + wave * quarter, r1 = r0 + quarter < c1 ? r0 + quarter : c1;
+    const int nt0 = blockIdx.y * NT2;
+    f32x16 acc[MT][NT2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) zero_acc<NT2>(acc[a]);
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    auto load_a = [&](int a, int64_t r, float (&v)[8]) {
+        const int hf = 32 * a + m;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r + 8 * kh + i;
+            v[i] = rr < r1 ? (hf < p.n_in ? gload1(p.H + rr * p.n_in + hf) : (hf == p.n_in ? 1.0f : 0.0f)) : 0.0f;
+        }
+    };
+    for (int64_t r = r0; r < r1; r += 16) {
+        v4i pb[NT2][3];
+#pragma unroll
+        for (int b = 0; b < NT2; ++b) {
+            const int zf = 32 * (nt0 + b) + m;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t rr = r + 8 * kh + i;
+                v[i] = (rr < r1 && zf < p.n_out) ? gload1(p.DZ + rr * p.n_out + zf) : 0.0f;
+            }
+            split8(v, pb[b][0], pb[b][1], pb[b][2]);
+        }
+        float va[8], vn[8];
+        load_a(0, r, va);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            if (a + 1 < MT) load_a(a + 1, r, vn);                                    // the next tile's rows are on their way during these MFMAs
+            v4i pa[3];
+            split8(va, pa[0], pa[1], pa[2]);
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int b = 0; b < NT2; ++b) acc[a][b] = mfma_bf16(pa[PA[term]], pb[b][PB[term]], acc[a][b]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) va[i] = vn[i];
+        }
+    }
+    float *out = p.part + (size_t)blockIdx.x * p.pstride;
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT2; ++b) {
+            if (wave > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][r * 64 + lane] = acc[a][b][r];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int zf = 32 * (nt0 + b) + m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[a][b][r];
+                    v = v + red[0][r * 64 + lane]; v = v + red[1][r * 64 + lane]; v = v + red[2][r * 64 + lane];
+                    const int hf = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (hf <= p.n_in && zf < p.n_out) out[(size_t)hf * p.n_out + zf] = v;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+#endif
+
+int launch_wgrad_f32(hipStream_t st, int64_t n, int64_t rpb, int parts, int64_t pstride, int n_in, int n_out, const float *H, const float *DZ, float *part)
+{
+    WgradArgs p{n, rpb, pstride, n_in, n_out, H, DZ, part};
+    const int mt = (n_in + 1 + 31) / 32, nt = (n_out + 31) / 32;
+    const int nt2 = nt >= 2 ? 2 : 1;
+    const dim3 grid((unsigned)parts, (unsigned)((nt + nt2 - 1) / nt2));
+#ifdef GNN_DIAG
+    static const bool split = getenv("GNN_TRAIN_WGRAD_SPLIT") != nullptr;
+#define GNN_WG_LAUNCH(M_, N_) if (split) hipLaunchKernelGGL((k_wgrad_split<M_, N_>), grid, 256, 0, st, p); else hipLaunchKernelGGL((k_wgrad_f32<M_, N_>), grid, 256, 0, st, p);
+#else
+#define GNN_WG_LAUNCH(M_, N_) hipLaunchKernelGGL((k_wgrad_f32<M_, N_>), grid, 256, 0, st, p);
+#endif
+#define GNN_WG_CASE(M_, N_)                                                                         \
+    if (mt == M_ && nt2 == N_) {                                                                    \
+        GNN_WG_LAUNCH(M_, N_)                                                                       \
+        HIPCHK(hipGetLastError());                                                                  \
+        return GNN_OK;                                                                              \
+    }
+    GNN_WG_CASE(3, 1) GNN_WG_CASE(3, 2) GNN_WG_CASE(4, 1) GNN_WG_CASE(4, 2) GNN_WG_CASE(5, 1) GNN_WG_CASE(5, 2)
+#undef GNN_WG_CASE
+#undef GNN_WG_LAUNCH
+    return gnn_fail(GNN_ERR_UNSUPPORTED, "no matrix-core weight-gradient instantiation for %d x %d tiles", mt, nt2);
+}
+inline bool tg_wgrad_covers(int n_in, int n_out) { const int mt = (n_in + 1 + 31) / 32; return mt >= 3 && mt <= 5 && n_out >= 32; }
+
 // The concat of one body (reference GNN/GNN.py:223-239) in one pass: [state | node labels | aggregated states | aggregated labels |
 // aggregated arc labels].  Everything but the state columns and their aggregate is loop-invariant and comes from the template.
 // Dropout in front of the first Dense layer (rate != 0) is applied on the way out.  The thread of column 0 also evaluates the
@@ -614,6 +1181,53 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
     if (__any(f) && (threadIdx.x & 63) == 0) gnn_flag_raise(flag);
 }
 
+// The same concat for many rows without Dropout in front of the first layer (state width a multiple of 4, <= 64): 16 lanes per row,
+// each gathering four aggregate columns (four arcs in flight, the fmaf chain in stored order) and copying four state columns and the
+// template columns; the while-condition of the body is evaluated by k_check (gnn_launch_check: same ascending-feature sums) beside it.
+// k_train_input gave the condition to the thread of column 0 - a 64-step chain that the other 63 lanes of its wave waited for - and ran
+// one thread per element: 3.2 ms per body at 1 M rows x 135 columns, this one about a quarter of that (profiles/r03_train_c3.txt).
+__global__ void __launch_bounds__(256) k_train_input_rows(int64_t n, int in_s, int Ds, int c_aggs, const float *__restrict__ tmpl, const float *__restrict__ state,
+                                                          const int32_t *__restrict__ indptr, const int32_t *__restrict__ adj_src,
+                                                          const float *__restrict__ adj_w, float *__restrict__ inp)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 4;
+    const int j = (int)(t & 15);
+    if (r >= n) return;
+    float *row = inp + r * in_s;
+    const int cc = 4 * j;
+    if (cc < Ds) {
+        const float4 own = *reinterpret_cast<const float4 *>(state + r * Ds + cc);
+        float4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int32_t e1 = indptr[r + 1];
+        for (int32_t e = indptr[r]; e < e1; e += 4) {
+            float w[4];
+            float4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = e + u < e1;
+                w[u] = in ? adj_w[e + u] : 0.0f;
+                x[u] = in ? *reinterpret_cast<const float4 *>(state + (int64_t)adj_src[e + u] * Ds + cc) : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u < e1) {
+                    a4.x = __builtin_fmaf(w[u], x[u].x, a4.x); a4.y = __builtin_fmaf(w[u], x[u].y, a4.y);
+                    a4.z = __builtin_fmaf(w[u], x[u].z, a4.z); a4.w = __builtin_fmaf(w[u], x[u].w, a4.w);
+                }
+        }
+        row[cc] = own.x; row[cc + 1] = own.y; row[cc + 2] = own.z; row[cc + 3] = own.w;
+        float *ag = row + c_aggs + cc;
+        ag[0] = a4.x; ag[1] = a4.y; ag[2] = a4.z; ag[3] = a4.w;
+    }
+    // template columns: [Ds, c_aggs) and [c_aggs + Ds, in_s)
+    const int n1 = c_aggs - Ds, nt = n1 + (in_s - c_aggs - Ds);
+    for (int q = j; q < nt; q += 16) {
+        const int c = q < n1 ? Ds + q : c_aggs + Ds + (q - n1);
+        row[c] = tmpl[r * in_s + c];
+    }
+}
+
 // End of one body of the backward pass in one launch.  Blocks < sg_blocks: aggregated_states = Adjacency^T . state  =>
 // d state[r] = d inp[r, :Ds] + sum over arcs (r -> dst) of w * d inp[dst, c_aggs:] (own-state columns of the concat + the transposed
 // aggregation over the by-source CSR).  The other blocks: the net's gradient vector += this call's chunk partials (sum_parts_block).
@@ -646,6 +1260,39 @@ __global__ void __launch_bounds__(256) k_state_grad_sum(int sg_blocks, int64_t n
     d_state[t] = d_inp[r * in_s + c] + acc;
 }
 
+
+// The transposed aggregation of k_state_grad_sum for many rows (state width a multiple of 4, <= 64): 16 lanes per source row, four columns
+// per lane, four arcs in flight per lane (sixteen dependent-free loads), same fmaf chain per element; the sum of the chunk partials runs as
+// its own launch then.  (One thread per element: 1.14 ms per body at 1 M rows x 64, profiles/r03_train_c3.txt.)
+__global__ void __launch_bounds__(256) k_state_grad_rows(int64_t n, int Ds, int in_s, int c_aggs, const float *__restrict__ d_inp, const int32_t *__restrict__ sip,
+                                                         const int32_t *__restrict__ sdst, const float *__restrict__ sw, float *__restrict__ d_state)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 4;
+    const int cc = 4 * (int)(t & 15);
+    if (r >= n || cc >= Ds) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int32_t e1 = sip[r + 1];
+    for (int32_t e = sip[r]; e < e1; e += 4) {
+        float w[4], x[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = e + u < e1;
+            w[u] = in ? sw[e + u] : 0.0f;
+            const float *q = d_inp + (int64_t)(in ? sdst[e + u] : 0) * in_s + c_aggs + cc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) x[u][v] = in ? q[v] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e + u < e1) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = __builtin_fmaf(w[u], x[u][v], acc[v]);
+            }
+    }
+    const float *own = d_inp + r * in_s + cc;
+    *reinterpret_cast<float4 *>(d_state + r * Ds + cc) = float4{own[0] + acc[0], own[1] + acc[1], own[2] + acc[2], own[3] + acc[3]};
+}
 
 __global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
 {
@@ -847,7 +1494,9 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
         c.hin[l] = h;
         if ((rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
         const bool sm = m->acts[l] == GNN_ACT_SOFTMAX;          // softmax needs the whole row: separate pass, in place
-        if (n > 0) {
+        if (n > 0 && tg_wide(width, no) && !sm && tg_many_rows(n)) {      // wide layer on many rows: matrix cores
+            if ((rc = launch_gemm_f32(st, buf, n, width, no, h, m->W[l], m->b[l], m->acts[l], 0, nullptr, 0.0f, nullptr, c.a[l]))) return rc;
+        } else if (n > 0) {
             constexpr int R = 8;
             const int ni_pad = (width + 3) & ~3;
             const size_t lds = dense_lds_bytes(R, ni_pad);
@@ -947,6 +1596,13 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         // weight + bias gradient tiles and d h_in = d z . W^T (back through Dropout l and, l > 0, the activation of layer l - 1) in one launch
         const int act_prev = l > 0 ? m->acts[l - 1] : -1;
         const bool prev_sm = act_prev == GNN_ACT_SOFTMAX;
+        if (tg_wide(no, ni) && tg_wgrad_covers(ni, no) && !prev_sm && tg_many_rows(n)) {      // both products of a wide layer on the matrix cores
+            if ((rc = launch_wgrad_f32(st, n, rpb, parts, ps, ni, no, c.hin[l], d, net.part + net.g_off[2 * l]))) return rc;
+            if ((rc = launch_gemm_f32(st, buf, n, no, ni, d, net.WT[l], nullptr, act_prev, 1, net.rate[l] != 0.0f ? c.keep[l] : nullptr, net.rate[l],
+                                      l > 0 ? c.a[l - 1] : nullptr, dprev))) return rc;
+            d = dprev;
+            continue;
+        }
         constexpr int R = 8;
         LayerBwd p;
         p.n = n; p.rows_per_block = rpb; p.pstride = ps;
@@ -965,7 +1621,10 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         d = dprev;
     }
     const unsigned sum_blocks = cdiv((int64_t)net.g_total, 64);
-    if (job && job->N > 0) {
+    if (job && tg_many_rows(job->N) && (job->Ds & 3) == 0 && job->Ds <= 64) {
+        hipLaunchKernelGGL(k_state_grad_rows, cdiv(job->N * 16, 256), 256, 0, st, job->N, job->Ds, job->in_s, job->c_aggs, d, job->sip, job->sdst, job->sw, job->d_state);
+        hipLaunchKernelGGL(k_sum_parts, sum_blocks, 256, 0, st, parts, (int64_t)net.g_total, net.part, net.grads);
+    } else if (job && job->N > 0) {
         const int sg = (int)cdiv(job->N * job->Ds, 256);
         hipLaunchKernelGGL(k_state_grad_sum, sg + sum_blocks, 256, 0, st, sg, job->N, job->Ds, job->in_s, job->c_aggs, d, job->sip, job->sdst, job->sw,
                            job->d_state, parts, (int64_t)net.g_total, net.part, net.grads);
@@ -1333,11 +1992,19 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
             if (r0 != 0.0f && (rc = buf.get(&keep0, (size_t)N * in_s))) return rc;
             const uint8_t *mk = d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)enq : nullptr;
             const uint64_t sd = seed + 7919ull * (uint64_t)(enq + 1);
-            // the input kernel of body i also evaluates gate i = condition(state_i, state_{i-1})
-            hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
-                               g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp, enq ? states[enq - 1] : (const float *)nullptr, l->thr,
-                               flags + (size_t)enq * GNN_FLAG_WORDS);
-            HIPCHK(hipGetLastError());
+            if (r0 == 0.0f && (Ds & 3) == 0 && Ds <= 64 && tg_many_rows(N)) {
+                // many rows: the concat 16 lanes per row, gate i = condition(state_i, state_{i-1}) by k_check beside it
+                hipLaunchKernelGGL(k_train_input_rows, cdiv(N * 16, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
+                                   g->sh->adj_w, inp);
+                HIPCHK(hipGetLastError());
+                if ((rc = gnn_launch_check(st, N, Ds, states[enq], enq ? states[enq - 1] : (const float *)nullptr, l->thr, flags + (size_t)enq * GNN_FLAG_WORDS))) return rc;
+            } else {
+                // the input kernel of body i also evaluates gate i = condition(state_i, state_{i-1})
+                hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
+                                   g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp, enq ? states[enq - 1] : (const float *)nullptr, l->thr,
+                                   flags + (size_t)enq * GNN_FLAG_WORDS);
+                HIPCHK(hipGetLastError());
+            }
             cx->caches.emplace_back();
             if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y))) return rc;
             states.push_back(y);

@@ -598,3 +598,52 @@ def test_lgnn_device_optimizer_matches_host_optimizer(mode):
         for net_h, net_d in ((gh.net_state, gd.net_state), (gh.net_output, gd.net_output)):
             for a, b in zip(net_h.get_weights(), net_d.get_weights()):
                 assert np.max(np.abs(a - b)) <= 5e-5 * max(1.0, np.max(np.abs(a)))
+
+
+@pytest.mark.parametrize('n,with_dropout', [(6000, False), (4500, True)])
+def test_wide_layers_on_the_matrix_cores_match_oracle(n, with_dropout):
+    """BASELINE configs[2] net shape (state_dim 64, 135 -> 128 -> 128 -> 64) on enough rows for the matrix-core products of the training
+    step (gnn_train.hip: k_gemm_f32 forward / d h_in, k_wgrad_f32 weight gradients, k_train_input_rows): loss, k and every gradient array
+    against the float64 oracle to 2e-4 of the array's largest entry (1e-3, the bar of the small-shape tests above, with Dropout in the
+    net).  Measured on this step (tools/dbg/train_acc.py, profiles/r03_train_c3.txt): split-bf16 products 1.1e-4, f32-MFMA chain 3.1e-4,
+    per-op FP32-ALU kernels 2.6e-4 - the bias gradients are the least accurate arrays in all three.  A repeated step gives the same bits
+    (per-chunk partials are added in a fixed order)."""
+    from GNN import _engine as e
+    rng = np.random.default_rng(n)
+    d, nl, al, max_it = 64, 3, 1, 3
+    arcs = random_arcs(rng, n, 4 * n, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    g['set_mask'] = rng.random(n) < 0.9
+    st = make_mlp(rng, al + 2 * (d + nl), [128, 128, d], 'selu', gain=0.7, bn_random=True)
+    ou = make_mlp(rng, d + nl, [2], 'softmax', batch_normalization=False)      # (BatchNormalization right after a softmax is ill-conditioned: 3e-3 in float32 whichever kernels run)
+    rate = 0.1 if with_dropout else 0.0                     # Dropout behind the first hidden layer: the d h_in epilogue of the wide product
+    st['dropout'], ou['dropout'] = ({1: rate} if with_dropout else {}), {}
+    mask = g['set_mask'] & g['output_mask']
+    m = int(mask.sum())
+    masks_s = [({1: rng.random((n, 128)) > rate} if with_dropout else {}) for _ in range(max_it)]
+    targets = np.eye(2)[rng.integers(0, 2, m)].astype(np.float32)
+    weights = (rng.uniform(0.5, 1.5, m) / m).astype(np.float32)
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    ref = tro.train_step(g, st, ou, d, max_it, 0.0, s0, masks_s, {}, targets, weights, loss='categorical_crossentropy', mean=False, graph_based=False)
+    graph = e.Graph(n, g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], np.asarray(g['arcs'])[:, 2:][g['arcT'][1]], nodes, mask)
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], False)
+    loop = e.Loop(graph, mst, mou, d, max_it, 0.0)
+    loop.set_state0(s0)
+    ms = np.concatenate([masks_s[k][1].astype(np.uint8).ravel() for k in range(max_it)]) if with_dropout else None
+    runs = []
+    for _ in range(2):
+        runs.append(loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0, None, dropout_state=[0, rate, 0, 0], dropout_output=[0, 0],
+                                    masks_state=ms, masks_output=None, bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=None))
+    res = runs[0]
+    assert res['k'] == ref['k'] == max_it
+    assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
+    pairs = list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output']))
+    scale = max(float(np.max(np.abs(want))) for _, want in pairs)           # the largest gradient entry of the step
+    tol = 1e-3 if with_dropout else 2e-4
+    for got, want in pairs:
+        assert got.shape == want.shape
+        # relative to the array's largest entry, but not below a tenth of the step's gradient scale (the small bias / BatchNormalization vectors)
+        assert np.max(np.abs(got - want)) <= tol * max(0.1 * scale, np.max(np.abs(want))), (got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)), scale)
+    for a, b in zip(runs[0]['grads_state'] + runs[0]['grads_output'], runs[1]['grads_state'] + runs[1]['grads_output']):
+        assert np.array_equal(a, b)

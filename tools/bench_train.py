@@ -1,5 +1,6 @@
-"""Wall time of one training step (gnn_loop_train_step through GNNgraphBased.training_step) on MUTAG batches of 32 and on
-a 100k-node synthetic graph.  Run on the GPU box: python tools/bench_train.py"""
+"""Wall time of one training step (gnn_loop_train_step through GNNgraphBased.training_step) on MUTAG batches of 32, on a 100k-node
+synthetic graph and (C3=1, or C3_ONLY=1 to skip the others) on the BASELINE configs[2] shape: 1M nodes / 10M arcs, state_dim 64,
+net_state 135 -> 128 -> 128 -> 64, 5 bodies.  Run on the GPU box: python tools/bench_train.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +12,41 @@ from GNN.MLP import MLP, set_seed
 from GNN.graph_class import GraphObject, GraphTensor
 import load_MUTAG
 
+def c3_shaped():
+    """gnn_loop_train_step on the bench workload (bench.py: graph, nets, initial state), 5 bodies, no optimizer step between the calls
+    (random-init weights give an expansive map: an update would change k), all-true masks, categorical cross-entropy."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from GNN import _engine as e
+    N, d = 1_000_000, 64
+    s = utils.syntheticGraph(N, 10, 3, 1, 2, seed=20261003)
+    n = s['n_nodes']
+    rng = np.random.default_rng(20261003)
+    st = bench.make_net(rng, 1 + 2 * (3 + d), [128, 128, d], 'selu')
+    ou = bench.make_net(rng, 3 + d, [2], 'softmax')
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    graph = e.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8))
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    loop = e.Loop(graph, mst, mou, d, 5, 0.0)
+    loop.set_state0(s0)
+    targets = np.eye(2, dtype=np.float32)[rng.integers(0, 2, n)]
+    weights = np.full(n, 1.0 / n, np.float32)
+    bn_s, bn_o = np.concatenate(st['weights'][-4:-2]), np.concatenate(ou['weights'][-4:-2])
+    step = lambda: loop.train_step(mst, mou, None, targets, weights, 0, None, dropout_state=[0, 0, 0, 0], dropout_output=[0, 0], bn_state=bn_s, bn_output=bn_o)
+    r = step()
+    reps = int(os.environ.get('C3_REPS', 3))
+    t = time.perf_counter()
+    for _ in range(reps):
+        r = step()
+    dt = (time.perf_counter() - t) / reps
+    print(f'C3-shaped gnn_loop_train_step (1M nodes / {s["n_arcs"]} arcs, 135->128->128->64 selu+BN, 67->2 softmax+BN, k={r["k"]}, loss {r["loss"]:.4f}): '
+          f'{1e3 * dt:.1f} ms/step, {n * r["k"] / dt:.3e} node-updates/s (fwd+bwd)   [GNN_TRAIN_MFMA={os.environ.get("GNN_TRAIN_MFMA", "default")}]', flush=True)
+
+
 set_seed(0)
+if os.environ.get('C3_ONLY'):
+    c3_shaped()
+    sys.exit(0)
 graphs = load_MUTAG.load(limit=128)
 batches = [GraphTensor.fromGraphObject(GraphObject.merge(graphs[i:i + 32], problem_based='g', aggregation_mode='average')) for i in range(0, 128, 32)]
 st = MLP(3 + 2 * 14, [32, 32, 14], 'selu', 'glorot_normal', 'zeros', dropout_rate=0.1, dropout_pos=0)
@@ -51,3 +86,6 @@ if True:
         r = g2.training_step(gt, True); print('  k', r['k'], 'loss', r['loss'])
     dt = (time.perf_counter() - t) / 5
     print(f'100k-node training_step: {1e3 * dt:.1f} ms/step (k={r["k"]}), {N * r["k"] / dt:.3e} node-updates/s (fwd+bwd)')
+
+if os.environ.get('C3'):
+    c3_shaped()
