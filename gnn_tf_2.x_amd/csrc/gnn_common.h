@@ -235,6 +235,9 @@ struct gnn_loop {
     int32_t *edge_dst = nullptr, *edge_rows = nullptr;
     float *edge_labels = nullptr;
     int64_t n_edge_masked = 0;
+    // incidence of the masked arcs by node (training backward): node -> (masked arc q << 1 | side), ascending q; side 0: the arc's
+    // destination half of the readout features, 1: its source half.  Lets the backward pass GATHER per node in a fixed order (no atomics).
+    int32_t *edge_inc_ptr = nullptr, *edge_inc = nullptr;
     int *gate_host = nullptr;               // pinned copy of one gate (early-exit check every GNN_BODY_CHUNK bodies)
     bool profiling = false;
     std::vector<hipEvent_t> ev;

@@ -1873,16 +1873,31 @@ extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, 
         if (arc_mask[e]) rows.push_back((int32_t)e);
     }
     HIPCHK(hipSetDevice(l->device));
-    (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels);
+    (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels); (void)hipFree(l->edge_inc_ptr); (void)hipFree(l->edge_inc);
     (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->otmp[0]); (void)hipFree(l->otmp[1]);
     l->feats = l->out = l->otmp[0] = l->otmp[1] = nullptr;
-    l->edge_dst = l->edge_rows = nullptr; l->edge_labels = nullptr;
+    l->edge_dst = l->edge_rows = nullptr; l->edge_labels = nullptr; l->edge_inc_ptr = l->edge_inc = nullptr;
     l->n_edge_masked = (int64_t)rows.size();
     int maxw_o = 1;
     for (int i = 1; i <= l->ou->n_layers; ++i) maxw_o = std::max(maxw_o, l->ou->dims[i]);
     int rc = dev_upload(&l->edge_dst, entry_dst, (size_t)g->E);
     if (!rc) rc = dev_upload(&l->edge_rows, rows.data(), rows.size());
     if (!rc && !g->arc_labels_orig_own) rc = dev_upload(&l->edge_labels, arc_labels, (size_t)g->E * g->AL);   // derived graphs own theirs
+    if (!rc) {      // masked arcs by endpoint (ascending masked-arc index): what the training backward gathers per node
+        std::vector<int32_t> src((size_t)g->E);
+        if (g->E) HIPCHK(hipMemcpy(src.data(), g->sh->adj_src, sizeof(int32_t) * (size_t)g->E, hipMemcpyDeviceToHost));
+        std::vector<int32_t> ptr((size_t)g->N + 1, 0), inc(2 * rows.size());
+        for (int32_t e : rows) { ++ptr[(size_t)entry_dst[e] + 1]; ++ptr[(size_t)src[e] + 1]; }
+        for (int64_t i = 0; i < g->N; ++i) ptr[i + 1] += ptr[i];
+        std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+        for (size_t q = 0; q < rows.size(); ++q) {
+            const int32_t e = rows[q];
+            inc[fill[entry_dst[e]]++] = (int32_t)(q << 1);
+            inc[fill[src[e]]++] = (int32_t)(q << 1) | 1;
+        }
+        rc = dev_upload(&l->edge_inc_ptr, ptr.data(), ptr.size());
+        if (!rc) rc = dev_upload(&l->edge_inc, inc.data(), inc.size());
+    }
     if (!rc) rc = dev_alloc(&l->feats, rows.size() * (size_t)l->ou->dims[0]);
     if (!rc) rc = dev_alloc(&l->out, rows.size() * (size_t)l->T);
     for (int b = 0; b < 2 && !rc; ++b) rc = dev_alloc(&l->otmp[b], rows.size() * (size_t)maxw_o);
@@ -2083,7 +2098,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
     if (l->gate_host) (void)hipHostFree(l->gate_host);
-    (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels);
+    (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels); (void)hipFree(l->edge_inc_ptr); (void)hipFree(l->edge_inc);
     (void)hipFree(l->sl_send); (void)hipFree(l->sl_state); (void)hipFree(l->sl_agg); (void)hipFree(l->sl_recv); (void)hipFree(l->agg_own);
     (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out); (void)hipFree(l->ng_part);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);

@@ -406,12 +406,9 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     // Experiment of round 3 (diagnostic build, GNN_FUSED_TILE16=1): 16-node tiles on v_mfma_f32_16x16x32_bf16, three waves per SIMD
     // (experiments/gnn_fused16_kernel.h).  Correct, and slower than this kernel at every size from 31 k to 500 k nodes:
     // every wave streams the weight image per 16 instead of 32 nodes and the vector L1 fill rate (64 B / clk / CU) becomes the bound.
-    int use16 = 0;
 #ifdef GNN_DIAG
     static const int tile16_env = getenv("GNN_FUSED_TILE16") ? atoi(getenv("GNN_FUSED_TILE16")) : 0;
-    use16 = tile16_env && split && !a.agg_in && m_has16(l->st) && tile16_covers(p, l->Ds);
-#endif
-#ifdef GNN_DIAG
+    const bool use16 = tile16_env && split && !a.agg_in && m_has16(l->st) && tile16_covers(p, l->Ds);
     if (use16) {
         GnnFusedArgs h = a;
         const gnn_mlp *m = l->st;

@@ -1778,21 +1778,25 @@ __global__ void k_scatter_label_grad(int64_t m, const int32_t *rows, const float
     d_nodes[(int64_t)rows[q] * NL + c] += d_feats[q * wf + Ds + c];
 }
 
-// GNNedgeBased backward: row q of d_feats = d [F[dst(e)] | F[src(e)] | arc label], e = rows[q]; F = [state | labels?].
-// Both endpoints receive their half (several arcs share a node: atomics); the arc-label columns are data.
-__global__ void k_scatter_edge_grad(int64_t m, const int32_t *rows, const int32_t *entry_dst, const int32_t *adj_src, const float *d_feats,
-                                    int we, int wn, int Ds, int NL, float *d_state, float *d_nodes)
+// GNNedgeBased backward: row q of d_feats = d [F[dst(e)] | F[src(e)] | arc label], e = rows[q]; F = [state | labels?].  Both endpoints
+// receive their half.  Several arcs share a node: every (node, column) is one thread that adds the halves of the node's masked arcs in
+// ascending arc order (gnn_loop_set_edge_readout builds the incidence lists) on top of what d_state / d_nodes hold - no float atomics,
+// so edge-based steps are run-to-run identical like the others (round 3; the scatter with atomicAdd was not).
+__global__ void k_gather_edge_grad(int64_t n, const int32_t *__restrict__ inc_ptr, const int32_t *__restrict__ inc, const float *__restrict__ d_feats, int we,
+                                   int wn, int Ds, int NL, float *d_state, float *d_nodes)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m * 2 * wn) return;
-    const int64_t q = t / (2 * wn);
-    int c = (int)(t - q * 2 * wn);
-    const int64_t e = rows[q];
-    const float v = d_feats[q * we + c];
-    const int64_t node = c < wn ? entry_dst[e] : adj_src[e];
-    if (c >= wn) c -= wn;
-    if (c < Ds) atomicAdd(d_state + node * Ds + c, v);
-    else if (d_nodes) atomicAdd(d_nodes + node * NL + (c - Ds), v);
+    if (t >= n * wn) return;
+    const int64_t node = t / wn;
+    const int c = (int)(t - node * wn);
+    float *dst = c < Ds ? d_state + node * Ds + c : (d_nodes ? d_nodes + node * NL + (c - Ds) : nullptr);
+    if (!dst) return;
+    float v = *dst;
+    for (int32_t i = inc_ptr[node]; i < inc_ptr[node + 1]; ++i) {
+        const int32_t x = inc[i];
+        v = v + d_feats[(int64_t)(x >> 1) * we + (x & 1) * wn + c];
+    }
+    *dst = v;
 }
 
 // acc[r, c] += d_inp[r, col0 + c]   (the loop-invariant aggregated arc labels receive gradient from every body)
@@ -2095,8 +2099,7 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
     if (l->edge_mode) {
         if (M) {
             const int wn = Ds + NLc;
-            hipLaunchKernelGGL(k_scatter_edge_grad, cdiv(M * 2 * wn, 256), 256, 0, st, M, l->edge_rows, l->edge_dst, g->sh->adj_src, d_feats, wf, wn,
-                               Ds, NL, d_state, d_nodes);
+            hipLaunchKernelGGL(k_gather_edge_grad, cdiv(N * wn, 256), 256, 0, st, N, l->edge_inc_ptr, l->edge_inc, d_feats, wf, wn, Ds, NL, d_state, d_nodes);
             HIPCHK(hipGetLastError());
         }
     } else if (M) {

@@ -317,6 +317,11 @@ def test_edge_based_training_step_matches_oracle(d):
     for got, want in list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output'])):
         assert got.shape == want.shape
         assert np.max(np.abs(got - want)) <= 1e-3 * max(1e-3, np.max(np.abs(want))), (got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)))
+    # run-to-run identical: the endpoint gradients are gathered per node in a fixed order (no float atomics) - learning rate 0, same masks
+    res2 = gnn.training_step(GraphTensor.fromGraphObject(go), mean=False, state0=s0,
+                             masks_state=np.concatenate([mk[0].astype(np.uint8).ravel() for mk in ms]), masks_output=mo[1].astype(np.uint8).ravel())
+    for a, b in zip(res['grads_state'] + res['grads_output'], res2['grads_state'] + res2['grads_output']):
+        assert np.array_equal(a, b)
     # and a few Adam steps reduce the loss of a learnable arc task (label = sign of the first arc label)
     cls = (arcs[:, 2] > np.median(arcs[:, 2])).astype(int)
     go2 = GraphObject(arcs=arcs, nodes=nodes, targets=np.eye(2)[cls], problem_based='a', aggregation_mode='average')
