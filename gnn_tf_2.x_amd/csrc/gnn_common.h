@@ -230,6 +230,10 @@ struct gnn_loop {
     float *ng_w = nullptr, *ng_out = nullptr, *ng_part = nullptr;   // ng_part [world, G, T]: per-rank partial readouts
     std::vector<int32_t> ng_key;
     std::vector<float> ng_w_host;
+    // graph readout folded into the persistent small-graph launch (gnn_small.hip): result [G, T] in pinned host memory, valid for the last run
+    float *ng_host = nullptr;
+    int ng_G = 0, ng_host_floats = 0;
+    bool ng_inlaunch = false;
     // edge-based readout (GNNedgeBased.apply_filters): entry -> CSR row, arc labels in original order, masked arc list
     bool edge_mode = false, edge_expected = false;
     int32_t *edge_dst = nullptr, *edge_rows = nullptr;

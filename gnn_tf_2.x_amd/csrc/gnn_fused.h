@@ -70,6 +70,13 @@ struct GnnSmallCtl {
     const float *nodes_own;  // node labels of the owned rows [n_rows, NL]
     const float *ow, *ob, *obn_scale, *obn_shift;   // net_output: W [wf, T], b [T], BatchNormalization scale / shift or nullptr
     int NL, NLc, T, oact;
+    // graph readout folded into the launch (NodeGraph^T . out, GNN.py:331-332; as k_readout), or ng_ip == nullptr: CSR over graphs of
+    // (node, weight), result [G, T] written to pinned host memory by workgroup 0 after one more grid barrier (word ro_word of `flags`)
+    const int32_t *ng_ip, *ng_node;
+    const float *ng_w;
+    float *ng_host;
+    int G, ro_word;
+    int ecache;              // arcs of a tile whose ids / weights may be kept in LDS (GNN_SMALL_ECACHE; 0: none)
 };
 bool gnn_small_launch(int layers, int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
                       hipStream_t st);

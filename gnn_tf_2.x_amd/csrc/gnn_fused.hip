@@ -474,10 +474,15 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     c.status = l->kfinal_dev + 1;
     c.host_result = l->kfinal_host;                                   // pinned, device-visible: no copy back
     c.max_iter = l->max_iter;
+    c.ecache = 1024;                                                  // = GNN_SMALL_ECACHE (gnn_small.hip)
+#ifdef GNN_DIAG
+    static const int ecache_env = getenv("GNN_SMALL_ECACHE") ? atoi(getenv("GNN_SMALL_ECACHE")) : 1024;
+    c.ecache = std::min(1024, ecache_env);
+#endif
     // Gate words: one per body, double-buffered by run parity at the start of the flag block.  This launch polls its own half
     // and zeroes the other half for the next run, so a run costs no memset; both halves are cleared by the host only after
     // something else (a per-body run) has used the block.
-    const size_t n_words = ((size_t)l->max_iter + 2 + 3) & ~(size_t)3;
+    const size_t n_words = ((size_t)l->max_iter + 3 + 3) & ~(size_t)3;      // gate of every body, + 1, + the barrier in front of the folded graph readout
     l->kfinal_host[1] = 0;                                            // status: cleared HERE, only ever set by the kernel (sticky)
     HIPCHK(hipMemsetAsync(l->kfinal_dev + 1, 0, sizeof(int), l->stream));
     if (!l->small_words_clean) {
@@ -499,9 +504,22 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
         c.obn_scale = ou->has_bn ? ou->bn_scale : nullptr; c.obn_shift = ou->has_bn ? ou->bn_shift : nullptr;
         c.NL = g->NL; c.NLc = l->NLc; c.T = l->T; c.oact = ou->acts[0];
         *output_done = true;
+        // graph readout in the same launch when a NodeGraph is already cached with the loop (gnn_loop_readout uploaded it after an earlier run)
+        l->ng_inlaunch = false;
+        if (l->ng_ip && l->ng_G > 0 && g->n_masked == g->n_rows) {
+            if (l->ng_host_floats < l->ng_G * l->T) {
+                if (l->ng_host) (void)hipHostFree(l->ng_host);
+                l->ng_host = nullptr; l->ng_host_floats = 0;
+                if (hipHostMalloc((void **)&l->ng_host, sizeof(float) * (size_t)l->ng_G * l->T) == hipSuccess) l->ng_host_floats = l->ng_G * l->T;
+            }
+            if (l->ng_host) {
+                c.ng_ip = l->ng_ip; c.ng_node = l->ng_node; c.ng_w = l->ng_w; c.ng_host = l->ng_host; c.G = l->ng_G; c.ro_word = l->max_iter + 1;
+                l->ng_inlaunch = true;                            // (cleared again by run_loops if the launch gives up)
+            }
+        }
     }
     const unsigned grid = (unsigned)((g->n_rows + 31) / 32);
-    const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 160 + 544 + 2048 + 4);    // tile, row pointers, epilogue vectors, head, scratch
+    const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 160 + 544 + 2048 + 2 * 1024 + 4);    // tile, row pointers, epilogue vectors, head, scratch, arc cache (GNN_SMALL_ECACHE)
     const int rnd = g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
 #ifdef GNN_DIAG
     static const char *small_stamp_file = getenv("GNN_SMALL_STAMPS");

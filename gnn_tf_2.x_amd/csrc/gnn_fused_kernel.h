@@ -606,9 +606,12 @@ __device__ __forceinline__ void zero_pad_columns(const GnnFusedArgs &a, float *X
 // own_from_lds (k_small_loop, bodies > 0): the tile is still in LDS from the previous body - zero padding and label columns are
 // unchanged, the new own state sits in columns c_aggs.. and only has to move to columns 0..
 // RND: entries per round of the narrow gather (ids / weights, then rows of RND entries requested together)
+// ecache_src / ecache_w (k_small_loop): the tile's arc ids / weights, entries [ecache_base, ...), already in LDS - the narrow gather then
+// pays one memory round trip per round (the rows) instead of two (ids, then rows)
 template <bool COH = false, int RND = 4>
 __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
-                                               int nvalid, int KP, int c_aggs, bool own_from_lds = false)
+                                               int nvalid, int KP, int c_aggs, bool own_from_lds = false, const int *ecache_src = nullptr,
+                                               const float *ecache_w = nullptr, int ecache_base = 0)
 {
     const int Ds = a.Ds, NLc = a.NLc;
     if (!own_from_lds) {
@@ -660,8 +663,8 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
 #pragma unroll
             for (int u = 0; u < RND; ++u) {
                 const int ee = e + u < end ? e + u : e;        // clamp: a real entry, result unused
-                w[u] = gload1(a.adj_w + ee);
-                xp[u] = a.state_cur + (int64_t)gload1(a.adj_src + ee) * Ds + cbeg;
+                w[u] = ecache_w ? ecache_w[ee - ecache_base] : gload1(a.adj_w + ee);
+                xp[u] = a.state_cur + (int64_t)(ecache_src ? ecache_src[ee - ecache_base] : gload1(a.adj_src + ee)) * Ds + cbeg;
             }
             float x[RND][16];
 #pragma unroll
@@ -952,6 +955,13 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
                                                  int c_aggs, int *moved_out = nullptr)
 {
     const int Ds = a.Ds, half = lane >> 5;
+    {   // the row stores first: they drain (write-through in the persistent loop, which waits for them before its barrier) while the
+        // condition is evaluated
+        float *dst = a.state_nxt + i0 * Ds;
+        const int total = nvalid * Ds;
+        RowCol rc(lane, Ds);
+        for (int t = lane; t < total; t += 64, rc.next()) sstore1<COH>(dst + t, X[rc.i * KP + c_aggs + rc.c]);
+    }
     const float *xo = X + (lane & 31) * KP, *xn = xo + c_aggs;
     float s_ = 0.0f;
     for (int f = 0; f < Ds; ++f) {
@@ -966,10 +976,6 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
     const int moved = (half == 0) && ((lane & 31) < nvalid) && (root > rhs);
     if (moved_out) *moved_out = __any(moved) ? 1 : 0;
     else if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
-    float *dst = a.state_nxt + i0 * Ds;
-    const int total = nvalid * Ds;
-    RowCol rc(lane, Ds);
-    for (int t = lane; t < total; t += 64, rc.next()) sstore1<COH>(dst + t, X[rc.i * KP + c_aggs + rc.c]);
 }
 
 __device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int KP, int c_aggs)

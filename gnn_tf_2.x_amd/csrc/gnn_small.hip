@@ -18,6 +18,8 @@
 
 namespace gnn_fused_dev {
 
+constexpr int GNN_SMALL_ECACHE = 1024;             // arcs of a tile whose ids / weights are kept in LDS (8 KB)
+
 // Dense layers with the packed A operands (gnn_fused_pack, exact image: [K-step][lane][tile]) held in REGISTERS for the whole
 // launch: the same v_mfma_f32_32x32x2_f32 chains as layer_from_lds / layer_from_regs with one 32-feature tile (NT == 1), i.e.
 // the oracle's k-ordered fmaf chains, without a weight load per body.
@@ -71,6 +73,8 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     float *hb = ep + 96;                                          // biases of the hidden layers [2][32]
     float *hw = ep + 160;                                         // net_output head: W [wf * T <= 512], then b | BN scale | BN shift [3][8]
     float *scr = hw + 544;                                        // scratch [2048]: the tile's final state rows and label rows
+    int *ec_src = reinterpret_cast<int *>(scr + 2048);            // the tile's arc ids / weights [GNN_SMALL_ECACHE], kept for every body
+    float *ec_w = scr + 2048 + GNN_SMALL_ECACHE;
     for (int t = lane; t < 3 * 32; t += 64) {
         const int which = t >> 5, f = t & 31;
         ep[t] = which == 0 ? a0.bias[LAYERS - 1][f] : (a0.bn_scale ? (which == 1 ? a0.bn_scale[f] : a0.bn_shift[f]) : 0.0f);
@@ -98,6 +102,13 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         const int last_ip = shfl_i(my_ip, nvalid);
         if (lane <= 32) ipt[lane] = lane <= nvalid ? my_ip : last_ip;
     }
+    // the tile's arcs (contiguous CSR entries of its 32 rows): ids and weights once into LDS when they fit - every body's gather then
+    // needs one memory round trip per round (the neighbour rows) instead of two
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int e_base = ipt[0], e_cnt = ipt[32] - e_base;
+    const bool ecached = e_cnt <= c.ecache;
+    if (ecached)
+        for (int t = lane; t < e_cnt; t += 64) { ec_src[t] = gload1(a0.adj_src + e_base + t); ec_w[t] = gload1(a0.adj_w + e_base + t); }
     // weights: once, into registers
     float w0[KK0], w1[16], w2[16];
 #pragma unroll
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         // body 0 gathers from the read-only initial state (no tile has to wait for the others' copies of it)
         a.state_cur = k == 0 ? c.init - a0.row_begin * Ds : ((k & 1) ? c.state1 : c.state0);
         a.state_nxt = ((k & 1) ? c.state0 : c.state1) + a0.row_begin * Ds;
-        load_tile_generic<true, RND>(a, X, ipt, i0, lane, nvalid, KP, c_aggs, k > 0);     // k > 0: the tile skeleton is still in LDS
+        load_tile_generic<true, RND>(a, X, ipt, i0, lane, nvalid, KP, c_aggs, k > 0, ecached ? ec_src : nullptr, ecached ? ec_w : nullptr, e_base);     // k > 0: the tile skeleton is still in LDS
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         SMALL_STAMP();                                               // body + 0: tile loaded (gather)
         const float *xb = X + (lane & 31) * KP + half;
@@ -287,11 +298,24 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
                 if (q < T) {
                     float r = v[q];
                     if (c.obn_scale) { const float t2 = r * hw[520 + q]; r = t2 + hw[528 + q]; }
-                    o[q] = r;
+                    sstore1<true>(o + q, r);                         // write-through: workgroup 0 may read it below (graph readout)
                 }
         }
     }
     SMALL_STAMP();                                                   // last: output stage
+    // ---- graph readout (GNN.py:331-332): out_graph[g, t] = sum over the (node, w) of graph g, ascending, fmaf(w, out[node, t]) - the
+    // arithmetic of k_readout - by workgroup 0 after one more grid barrier; the result goes straight to pinned host memory -------------
+    if (c.ng_ip) {
+        if (arrive_and_gate(c.ro_word, 0) < 0) return;
+        if (blockIdx.x == 0)
+            for (int t = lane; t < c.G * c.T; t += 64) {
+                const int gi = t / c.T, ci = t - gi * c.T;
+                float acc = 0.0f;
+                for (int e = gload1(c.ng_ip + gi); e < gload1(c.ng_ip + gi + 1); ++e)
+                    acc = __builtin_fmaf(gload1(c.ng_w + e), sload1<true>(c.out + (int64_t)gload1(c.ng_node + e) * c.T + ci), acc);
+                c.ng_host[t] = acc;
+            }
+    }
 }
 
 template <int LAYERS, int ACT>

@@ -249,6 +249,18 @@ def test_graph_based_readout_and_errors():
     assert k == kc and np.array_equal(s, sc)
     assert o.shape == (3, 2) and np.array_equal(o, corc.readout(go.NodeGraph, on))
     np.testing.assert_allclose(o, orc.loop_graph(gd, st, ou, 0, 15, 0.01, dtype=np.float64)[2], atol=1e-5)
+    # repeated Loops on ONE device-resident graph: from the second on the NodeGraph is cached with the device loop and the persistent
+    # small-graph launch folds the readout in (gnn_small.hip: one more grid barrier, result in pinned host memory) - same bits as k_readout
+    from GNN.graph_class import GraphTensor
+    gt = GraphTensor.fromGraphObject(go)
+    for _ in range(3):
+        k2, s2, o2 = gnn.Loop(gt)
+        assert k2 == kc and np.array_equal(s2, sc) and np.array_equal(o2, o)
+    # ... and a changed NodeGraph (other weights) on the same device graph is noticed: separate readout once, then folded in again
+    gt.NodeGraph = (np.asarray(go.NodeGraph) * 2.0).astype(np.float32)
+    if hasattr(gt, '_ng_csr'): gt._ng_csr = None
+    for _ in range(3):
+        assert np.array_equal(gnn.Loop(gt)[2], corc.readout(gt.NodeGraph, on))
     node_only = GraphObject(arcs=go.arcs, nodes=go.nodes, targets=np.zeros((go.nodes.shape[0], 2)))
     with pytest.raises(ValueError):
         gnn.Loop(node_only)                                        # reference GNN.py:322
