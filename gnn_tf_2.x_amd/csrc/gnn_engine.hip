@@ -559,6 +559,8 @@ int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const
     const int64_t threads = n_rows * lpr;
     const unsigned grid = (unsigned)std::min<int64_t>(cdiv(threads, 256), 256 * 32);
     const bool indexed = idx != nullptr;
+    // (A one-lane-per-row form with eight entries in flight for the 8-column slices of the feature-sliced exchange was measured in round 3:
+    //  257 us against 203 us for this kernel's two lanes per row - profiles/r03_exchange_layouts.txt - and removed.)
     if (vec4 && indexed) hipLaunchKernelGGL((k_spmm<4, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
     else if (vec4) hipLaunchKernelGGL((k_spmm<4, false>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
     else if (indexed) hipLaunchKernelGGL((k_spmm<1, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
