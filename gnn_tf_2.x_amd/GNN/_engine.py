@@ -219,12 +219,16 @@ class Graph:
     def derive(self, extra: int) -> 'Graph':
         h = C.c_void_p()
         _check(lib().gnn_graph_derive(self._h, C.c_int(extra), C.byref(h)))
-        return Graph(None, None, None, None, None, None, None, None, _handle=h)
+        d = Graph(None, None, None, None, None, None, None, None, _handle=h)
+        d._base = self            # a derived graph uses arrays of its base (CSR, boundary rows): keep it alive
+        return d
 
     def derive_edge(self, extra_nodes: int, extra_arcs: int) -> 'Graph':
         h = C.c_void_p()
         _check(lib().gnn_graph_derive_edge(self._h, C.c_int(extra_nodes), C.c_int(extra_arcs), C.byref(h)))
-        return Graph(None, None, None, None, None, None, None, None, _handle=h)
+        d = Graph(None, None, None, None, None, None, None, None, _handle=h)
+        d._base = self
+        return d
 
     def set_arc_order(self, arc_id, arc_labels_orig) -> None:
         arc_id = np.ascontiguousarray(arc_id, dtype=np.int32)

@@ -119,6 +119,12 @@ struct gnn_graph_shared {
     // (gnn_graph_set_arc_order)
     int32_t *arc_id = nullptr;
     float *arc_labels_orig = nullptr;
+    // Adjacency of the WHOLE graph (CSR by destination over all N_global rows, global source ids): operand of the feature-sliced
+    // exchange (gnn_loop_set_slice_exchange), where a rank aggregates its columns of the state for every node.  Shared with the
+    // graphs derived from this one (LGNN layers > 0 on sliced shards use the same adjacency).
+    int32_t *full_indptr = nullptr, *full_src = nullptr;
+    float *full_w = nullptr;
+    int64_t full_rows = 0;
 };
 
 struct gnn_graph {
@@ -131,7 +137,8 @@ struct gnn_graph {
     // boundary ("halo") exchange plan of a shard created by gnn_graph_create_halo, else halo_world == 0
     int halo_world = 0, halo_rank = 0;
     int64_t halo_block = 0, halo_count = 0;      // rows per rank block in the replica, boundary rows this rank sends
-    int32_t *halo_send = nullptr;                // device [halo_count]: owned-row indices of the boundary rows, ascending
+    int32_t *halo_send = nullptr;                // device [halo_count]: owned-row indices of the boundary rows, ascending (derived graphs: the base's array, see halo_send_owned)
+    bool halo_send_owned = true;
     int64_t nodes_rows = 0;                      // rows allocated for `nodes` (>= N; derived graphs are padded for the all-gather)
     gnn_graph_shared *sh = nullptr;
     float *nodes = nullptr;   // [N, NL]
@@ -140,11 +147,6 @@ struct gnn_graph {
     float *arc_labels_own = nullptr, *arc_labels_orig_own = nullptr;
     int base_AL = 0;
     uint64_t label_version = 1;   // bumped whenever node / arc labels are rewritten (gnn_graph_update_labels)
-    // Adjacency of the WHOLE graph (CSR by destination over all N_global rows, global source ids): operand of the feature-sliced
-    // exchange (gnn_loop_set_slice_exchange), where a rank aggregates its columns of the state for every node
-    int32_t *full_indptr = nullptr, *full_src = nullptr;
-    float *full_w = nullptr;
-    int64_t full_rows = 0;
     // recorded behind the creation-time zero fills of a derived graph's label arrays (engine fill stream); streams that touch the
     // labels wait for it on the device (gnn_graph_wait_ready), host readers synchronise on it.  nullptr: nothing to wait for.
     hipEvent_t ready = nullptr;

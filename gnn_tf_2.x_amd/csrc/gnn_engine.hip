@@ -349,7 +349,7 @@ __global__ void k_feats(int64_t n_masked, const int32_t *__restrict__ masked_row
 __global__ void k_feats_edge(int64_t n_masked, const int32_t *__restrict__ rows, const int32_t *__restrict__ entry_dst,
                              const int32_t *__restrict__ adj_src, const float *s0, const float *s1, const int *kfinal, int Ds,
                              const float *__restrict__ nodes, int NL, int NLc, const float *__restrict__ arc_labels, int AL,
-                             float *__restrict__ feats)
+                             float *__restrict__ feats, int64_t own_off)
 {
     const int wn = Ds + NLc, wf = 2 * wn + AL;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,7 +360,7 @@ __global__ void k_feats_edge(int64_t n_masked, const int32_t *__restrict__ rows,
     const int64_t e = rows[m];
     float v;
     if (c < 2 * wn) {
-        const int64_t node = c < wn ? entry_dst[e] : adj_src[e];
+        const int64_t node = c < wn ? own_off + entry_dst[e] : adj_src[e];      // destination: owned row -> row of the replica; source: already in the replica's index space
         if (c >= wn) c -= wn;
         v = c < Ds ? state[node * Ds + c] : nodes[node * NL + (c - Ds)];
     } else {
@@ -610,7 +610,7 @@ int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state,
     const gnn_graph *g = l->g;
     const int64_t tot = l->n_edge_masked * l->ou->dims[0];
     hipLaunchKernelGGL(k_feats_edge, cdiv(tot, 256), 256, 0, st, l->n_edge_masked, l->edge_rows, l->edge_dst, g->sh->adj_src, state, state,
-                       l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, g->arc_labels_orig_own ? g->arc_labels_orig_own : l->edge_labels, g->AL, feats);
+                       l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, g->arc_labels_orig_own ? g->arc_labels_orig_own : l->edge_labels, g->AL, feats, l->own_off);
     HIPCHK(hipGetLastError());
     return GNN_OK;
 }
@@ -661,6 +661,7 @@ static void graph_release_shared(gnn_graph_shared *sh)
     (void)hipFree(sh->adj_w); (void)hipFree(sh->arc_w); (void)hipFree(sh->arc_labels); (void)hipFree(sh->mask);
     (void)hipFree(sh->src_indptr); (void)hipFree(sh->src_dst); (void)hipFree(sh->src_w);
     (void)hipFree(sh->arc_id); (void)hipFree(sh->arc_labels_orig);
+    (void)hipFree(sh->full_indptr); (void)hipFree(sh->full_src); (void)hipFree(sh->full_w);
     delete sh;
 }
 
@@ -792,15 +793,13 @@ extern "C" int gnn_graph_derive(const gnn_graph *base, int extra, gnn_graph **ou
 {
     ARGCHK(base && out && extra >= 0, "bad arguments");
     *out = nullptr;
-    ARGCHK(!base->halo_world, "LGNN relabelling is not available on boundary-exchange shards (use full-replica shards)");
     HIPCHK(hipSetDevice(base->device));
     gnn_graph *g = new gnn_graph(*base);
     g->sh->refs++;
     g->NL = base->base_NL + extra;
     g->nodes = nullptr;
     g->arc_labels_own = g->arc_labels_orig_own = nullptr;      // never share the owned arc labels of a derived base
-    g->halo_send = nullptr;
-    g->full_indptr = nullptr; g->full_src = nullptr; g->full_w = nullptr; g->full_rows = 0;      // (owned by the base; set again with gnn_graph_set_full_adjacency)
+    g->halo_send_owned = false;                                // (boundary-exchange shards: same shard, same boundary rows; the base outlives its derived graphs' use of them)
     g->AL = base->base_AL;
     g->nodes_rows = derived_node_rows(g->N);
     g->ready = nullptr;                                        // (the base's event, if any, stays the base's)
@@ -880,13 +879,14 @@ extern "C" int gnn_graph_set_full_adjacency(gnn_graph *g, int64_t n_global, cons
     for (int64_t i = 0; i < n_global; ++i) ARGCHK(indptr[i] <= indptr[i + 1], "indptr must be non-decreasing");
     for (int64_t q = 0; q < e; ++q) ARGCHK(adj_src[q] >= 0 && adj_src[q] < n_global, "adj_src[%lld] out of range", (long long)q);
     HIPCHK(hipSetDevice(g->device));
-    (void)hipFree(g->full_indptr); (void)hipFree(g->full_src); (void)hipFree(g->full_w);
-    g->full_indptr = nullptr; g->full_src = nullptr; g->full_w = nullptr;
-    int rc = dev_upload(&g->full_indptr, indptr, (size_t)n_global + 1);
-    if (!rc) rc = dev_upload(&g->full_src, adj_src, (size_t)e);
-    if (!rc) rc = dev_upload(&g->full_w, adj_w, (size_t)e);
+    gnn_graph_shared *sh = g->sh;                  // shared with the graphs derived from g
+    (void)hipFree(sh->full_indptr); (void)hipFree(sh->full_src); (void)hipFree(sh->full_w);
+    sh->full_indptr = nullptr; sh->full_src = nullptr; sh->full_w = nullptr; sh->full_rows = 0;
+    int rc = dev_upload(&sh->full_indptr, indptr, (size_t)n_global + 1);
+    if (!rc) rc = dev_upload(&sh->full_src, adj_src, (size_t)e);
+    if (!rc) rc = dev_upload(&sh->full_w, adj_w, (size_t)e);
     if (rc) return rc;
-    g->full_rows = n_global;
+    sh->full_rows = n_global;
     return GNN_OK;
 }
 
@@ -894,8 +894,8 @@ extern "C" int gnn_graph_destroy(gnn_graph *g)
 {
     if (!g) return GNN_OK;
     (void)hipSetDevice(g->device);
-    (void)hipFree(g->arc_labels_own); (void)hipFree(g->arc_labels_orig_own); (void)hipFree(g->halo_send);
-    (void)hipFree(g->full_indptr); (void)hipFree(g->full_src); (void)hipFree(g->full_w);
+    (void)hipFree(g->arc_labels_own); (void)hipFree(g->arc_labels_orig_own);
+    if (g->halo_send_owned) (void)hipFree(g->halo_send);
     (void)hipFree(g->nodes);
     if (g->ready) (void)hipEventDestroy(g->ready);
     graph_release_shared(g->sh);
@@ -1537,7 +1537,7 @@ static int slice_step_aggregate(gnn_loop *l, int k)
 {
     const gnn_graph *g = l->g;
     const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
-    int rc = gnn_launch_spmm(l->stream, g->full_rows, g->full_indptr, g->full_src, g->full_w, l->sl_state, l->Cs, l->Cs, l->sl_agg, l->Cs, gate, l->world);
+    int rc = gnn_launch_spmm(l->stream, g->sh->full_rows, g->sh->full_indptr, g->sh->full_src, g->sh->full_w, l->sl_state, l->Cs, l->Cs, l->sl_agg, l->Cs, gate, l->world);
     if (rc) return rc;
     return slice_alltoall(l, 1);
 }
@@ -1563,7 +1563,7 @@ extern "C" int gnn_loop_set_slice_exchange(gnn_loop *l, int on)
     if (!on) { l->slice_mode = false; return GNN_OK; }
     ARGCHK(l->world > 1, "the feature-sliced exchange needs a communicator");
     ARGCHK(l->Ds % l->world == 0, "state width %d is not a multiple of the world size %d", l->Ds, l->world);
-    ARGCHK(l->g->full_indptr, "call gnn_graph_set_full_adjacency first");
+    ARGCHK(l->g->sh->full_indptr, "call gnn_graph_set_full_adjacency first (on this graph or on the graph it was derived from)");
     ARGCHK(!l->g->halo_world, "not on a boundary-exchange shard");
     HIPCHK(hipSetDevice(l->device));
     l->Cs = l->Ds / l->world;
@@ -1677,7 +1677,7 @@ static int loop_finish(gnn_loop *l, bool finalize, bool output_done)
             const int we = l->ou->dims[0];
             const int64_t tot = l->n_edge_masked * we;
             hipLaunchKernelGGL(k_feats_edge, cdiv(tot, 256), 256, 0, st, l->n_edge_masked, l->edge_rows, l->edge_dst, g->sh->adj_src, l->state[0],
-                               l->state[1], l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, g->arc_labels_orig_own ? g->arc_labels_orig_own : l->edge_labels, g->AL, l->feats);
+                               l->state[1], l->kfinal_dev, l->Ds, g->nodes, g->NL, l->NLc, g->arc_labels_orig_own ? g->arc_labels_orig_own : l->edge_labels, g->AL, l->feats, l->own_off);
             HIPCHK(hipGetLastError());
             rc = launch_mlp(st, l->ou, l->n_edge_masked, l->feats, we, l->out, l->T, l->otmp[0], l->otmp[1], nullptr, 1);
             if (rc) return rc;
@@ -1869,11 +1869,13 @@ extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, 
 {
     ARGCHK(l && (l->g->E == 0 || (entry_dst && arc_mask && (arc_labels || l->g->AL == 0 || l->g->arc_labels_orig_own))), "bad arguments");
     ARGCHK(l->edge_expected, "net_output input width %d is not the edge-based 2 (NL + D) + AL", l->ou->dims[0]);
-    ARGCHK(l->world == 1 && l->g->n_rows == l->g->N, "the edge-based readout is single-GPU only");
+    // Sharded loops (round 3): a rank reads out the arcs of its OWN CSR rows - entry_dst are owned-row indices, the source endpoint is in
+    // the replica's index space like every adj_src - so the per-rank outputs, in rank order, are the unsharded output.  (Training and
+    // the arc-side LGNN relabelling stay single-GPU.)
     const gnn_graph *g = l->g;
     std::vector<int32_t> rows;
     for (int64_t e = 0; e < g->E; ++e) {
-        ARGCHK(entry_dst[e] >= 0 && entry_dst[e] < g->N, "entry_dst[%lld]=%d outside [0,%lld)", (long long)e, entry_dst[e], (long long)g->N);
+        ARGCHK(entry_dst[e] >= 0 && entry_dst[e] < g->n_rows, "entry_dst[%lld]=%d outside the %lld owned rows", (long long)e, entry_dst[e], (long long)g->n_rows);
         if (arc_mask[e]) rows.push_back((int32_t)e);
     }
     HIPCHK(hipSetDevice(l->device));
@@ -1887,7 +1889,7 @@ extern "C" int gnn_loop_set_edge_readout(gnn_loop *l, const int32_t *entry_dst, 
     int rc = dev_upload(&l->edge_dst, entry_dst, (size_t)g->E);
     if (!rc) rc = dev_upload(&l->edge_rows, rows.data(), rows.size());
     if (!rc && !g->arc_labels_orig_own) rc = dev_upload(&l->edge_labels, arc_labels, (size_t)g->E * g->AL);   // derived graphs own theirs
-    if (!rc) {      // masked arcs by endpoint (ascending masked-arc index): what the training backward gathers per node
+    if (!rc && l->world == 1 && g->n_rows == g->N) {      // masked arcs by endpoint (ascending masked-arc index): what the (single-GPU) training backward gathers per node
         std::vector<int32_t> src((size_t)g->E);
         if (g->E) HIPCHK(hipMemcpy(src.data(), g->sh->adj_src, sizeof(int32_t) * (size_t)g->E, hipMemcpyDeviceToHost));
         std::vector<int32_t> ptr((size_t)g->N + 1, 0), inc(2 * rows.size());
@@ -2011,7 +2013,7 @@ static int relabel_own(gnn_graph *dst, const gnn_graph *base, const gnn_loop *fr
     ARGCHK(dst->sh == base->sh, "dst must be derived from base");
     if (!from->ran) return gnn_fail(GNN_ERR_STATE, "the source loop has not run");
     ARGCHK(from->g->sh == base->sh, "the source loop ran on an unrelated graph");
-    ARGCHK(!base->halo_world, "LGNN relabelling is not available on boundary-exchange shards");
+    ARGCHK(!base->halo_world || (dst->halo_world == base->halo_world && dst->halo_block == base->halo_block), "dst is not a boundary-exchange shard like base");
     // edge-based layers put the output on the ARC labels (LGNN.py:253-254), node/graph-based ones on the node labels (:256)
     const bool arc_side = from->edge_mode;
     ARGCHK(!arc_side || from->world == 1, "edge-based LGNN stacks are single-GPU only");
@@ -2045,13 +2047,30 @@ static int relabel_own(gnn_graph *dst, const gnn_graph *base, const gnn_loop *fr
     return GNN_OK;
 }
 
+// boundary-exchange shards: the rank's boundary rows of the NEW labels go into its block of the index space (then every rank's block is
+// exchanged like the state rows of an iteration: all-gather of blocks / device copies in a loopback group)
+static int relabel_pack_boundary(gnn_graph *dst, const gnn_loop *from)
+{
+    if (!dst->halo_world || !dst->halo_count) return GNN_OK;
+    const int64_t tot = dst->halo_count * dst->NL;
+    float *block = dst->nodes + ((size_t)from->shard_rows + (size_t)dst->halo_rank * dst->halo_block) * dst->NL;
+    hipLaunchKernelGGL(k_pack_rows, cdiv(tot, 256), 256, 0, from->stream, dst->halo_count, dst->NL, dst->halo_send, dst->nodes, block);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
 extern "C" int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output)
 {
     ARGCHK(from, "bad arguments");
     if (from->comm && from->comm->grp && from->world > 1) return gnn_fail(GNN_ERR_STATE, "loopback group: use gnn_graph_update_labels_group");
     int rc = relabel_own(dst, base, from, get_state, get_output);
     if (rc) return rc;
-    if (from->world > 1) {      // every rank relabelled its own rows: all-gather whole shards of the new label rows, in place
+    if (from->world > 1 && dst->halo_world) {      // boundary-exchange shards: all-gather of the boundary blocks of the new labels, in place
+        if ((rc = relabel_pack_boundary(dst, from))) return rc;
+        const size_t cnt = (size_t)dst->halo_block * dst->NL;
+        float *blocks = dst->nodes + (size_t)from->shard_rows * dst->NL;
+        if (cnt) NCCLCHK(g_rccl.AllGather(blocks + cnt * from->rank, blocks, cnt, NCCL_FLOAT32, from->comm->nccl, from->stream));
+    } else if (from->world > 1) {      // every rank relabelled its own rows: all-gather whole shards of the new label rows, in place
         const size_t cnt = (size_t)from->shard_rows * dst->NL;
         ARGCHK((int64_t)from->shard_rows * from->world <= dst->nodes_rows, "derived graph too small for the sharded relabelling");
         NCCLCHK(g_rccl.AllGather(dst->nodes + cnt * from->rank, dst->nodes, cnt, NCCL_FLOAT32, from->comm->nccl, from->stream));
@@ -2069,6 +2088,21 @@ extern "C" int gnn_graph_update_labels_group(gnn_graph **dsts, gnn_graph *const 
                "froms must be the %d ranks of one loopback group, in rank order", n);
     int rc = 0;
     for (int r = 0; r < n; ++r) if ((rc = relabel_own(dsts[r], bases[r], froms[r], get_state, get_output))) return rc;
+    if (dsts[0]->halo_world) {          // boundary-exchange shards: every rank's block of boundary label rows into every other rank's copy
+        for (int r = 0; r < n; ++r) {
+            ARGCHK(dsts[r]->halo_world == n && dsts[r]->halo_block == dsts[0]->halo_block && dsts[r]->NL == dsts[0]->NL, "ranks hold differently shaped boundary-exchange shards");
+            if ((rc = relabel_pack_boundary(dsts[r], froms[r]))) return rc;
+        }
+        const size_t cnt = (size_t)dsts[0]->halo_block * dsts[0]->NL;
+        for (int r = 0; r < n && cnt; ++r) {
+            const size_t off = ((size_t)froms[r]->shard_rows + (size_t)r * dsts[r]->halo_block) * dsts[r]->NL;
+            for (int p = 0; p < n; ++p)
+                if (p != r) HIPCHK(hipMemcpyAsync(dsts[p]->nodes + off, dsts[r]->nodes + off, sizeof(float) * cnt, hipMemcpyDeviceToDevice, froms[r]->stream));
+        }
+        HIPCHK(hipStreamSynchronize(froms[0]->stream));
+        for (int r = 0; r < n; ++r) dsts[r]->label_version++;
+        return GNN_OK;
+    }
     for (int r = 0; r < n; ++r) {
         const size_t cnt = (size_t)froms[r]->shard_rows * dsts[r]->NL;
         ARGCHK((int64_t)froms[r]->shard_rows * n <= dsts[r]->nodes_rows, "derived graph too small for the sharded relabelling");

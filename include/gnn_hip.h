@@ -82,8 +82,10 @@ int gnn_graph_create_from_arcs(int64_t n_nodes, int64_t n_arcs, const int32_t *a
  * dst.nodes <- [base.nodes | state of `from` (if get_state) | scatter(mask, output of `from`) (if get_output)].
  * `dst` must have been created by gnn_graph_derive(base, extra) with extra = get_state*Ds + get_output*T. */
 int gnn_graph_derive(const gnn_graph *base, int extra_node_label_dims, gnn_graph **out);
-/* Sharded graphs (full-replica shards): every rank relabels its own rows, then the new label rows are all-gathered (RCCL
- * communicator: call on every rank; loopback group: gnn_graph_update_labels_group below). */
+/* Sharded graphs: every rank relabels its own rows, then the new label rows are exchanged - whole shards (full-replica shards) or
+ * the rank's boundary rows into its block (gnn_graph_create_halo shards) - RCCL communicator: call on every rank; loopback group:
+ * gnn_graph_update_labels_group below.  A derived graph's labels are zero until then; that fill is ordered on the device before
+ * whatever touches the labels first (no call waits for it on the host). */
 int gnn_graph_update_labels(gnn_graph *dst, const gnn_graph *base, const gnn_loop *from, int get_state, int get_output);
 /* Edge-based LGNN (reference GNN/LGNN.py:253-254: the output of an edge-based layer widens the ARC labels, its state the
  * node labels).  gnn_graph_set_arc_order gives the original graph what the arc side needs: arc_id [n_arcs] = arc of every
@@ -120,8 +122,10 @@ int gnn_mlp_destroy(gnn_mlp *m);
  *   max_iter, thr  max_iteration, state_threshold (GNN.py:61-62)
  * gnn_loop_set_state0: injected initial state [n_rows owned, state_dim] (the reference draws tf.random.normal(stddev=0.1),
  * GNN.py:262, whose stream cannot be reproduced); NULL draws N(0, 0.1^2) from the engine's own counter RNG with `seed`.
- * gnn_loop_run: runs the whole loop on the device; the host synchronises at its end (and reads one gate every 16 bodies so
- * that a converged loop stops enqueuing).  *k_out = number of executed iterations as float (GNN.py:267).  This is the
+ * gnn_loop_run: runs the whole loop on the device.  Bodies are enqueued 16 at a time without waiting for them (a body whose gate is
+ * closed returns at once); after each 16 the host reads the next body's gate so that a converged loop stops enqueuing, and it
+ * synchronises once at the end.  Small graphs (all tiles resident, nets <= 32 wide) take ONE persistent launch for the whole loop,
+ * the output stage and - once a NodeGraph is cached with the loop by an earlier gnn_loop_readout - the graph readout.  *k_out = number of executed iterations as float (GNN.py:267).  This is the
  * inference Loop (training=False); training != 0 is GNN_ERR_UNSUPPORTED here: the training-mode Loop and its backward pass
  * are gnn_loop_train_forward / gnn_loop_train_backward / gnn_loop_train_step below.
  */
@@ -132,7 +136,9 @@ int gnn_loop_run(gnn_loop *l, int training, float *k_out);
 int gnn_loop_get_state(const gnn_loop *l, float *state_out /* [n_rows, Ds] */);
 int gnn_loop_get_output(const gnn_loop *l, float *out /* [n_masked, T] */, int64_t *n_masked);
 /* GNNgraphBased.Loop readout (GNN/GNN.py:331-332, LGNN.py:278): out_graph = NodeGraph^T . out_nodes.
- * NodeGraph^T is passed in CSR form over graphs: ng_indptr[G+1], ng_node (ascending), ng_w. */
+ * NodeGraph^T is passed in CSR form over graphs: ng_indptr[G+1], ng_node (ascending), ng_w.  The arrays are kept with the loop (and
+ * compared on every call): when the persistent small-graph launch of the last run has already computed the readout for the same
+ * NodeGraph, the call only copies the result. */
 int gnn_loop_readout(const gnn_loop *l, int n_graphs, const int32_t *ng_indptr, const int32_t *ng_node,
                      const float *ng_w, float *out_graph /* [G, T] */);
 /* GNNedgeBased.apply_filters (GNN/GNN.py:289-302): switches the output stage of this loop to the per-arc readout.  Row e of

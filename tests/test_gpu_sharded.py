@@ -174,10 +174,13 @@ def test_sharded_graph_readout(world):
     assert np.max(np.abs(got - want)) < 1e-6
 
 
+@pytest.mark.parametrize('sliced', [False, True, 'halo'])
 @pytest.mark.parametrize('world', [2, 3])
-def test_sharded_lgnn_relabelling(world):
+def test_sharded_lgnn_relabelling(world, sliced):
     """LGNN.update_graph (LGNN.py:227-260) on shards: every rank relabels its own rows, the new label rows are exchanged, the
-    next layer runs on them.  Two layers, get_state and get_output both on; bit-equal to the single-GPU stack."""
+    next layer runs on them.  Two layers, get_state and get_output both on; bit-equal to the single-GPU stack.  sliced: both layers
+    use the feature-sliced exchange; the derived graphs of layer 1 share the whole-graph adjacency of their base (no second upload).
+    'halo': boundary-exchange shards - the relabelled BOUNDARY rows are exchanged block-wise, like the state rows of an iteration."""
     e = _engine()
     rng = np.random.default_rng(9 + world)
     n, d, nl, al = 700, 6, 3, 1
@@ -189,27 +192,42 @@ def test_sharded_lgnn_relabelling(world):
     mask = np.logical_and(g['set_mask'], g['output_mask'])
     indptr, adj_src, adj_w, arc_w, arc_lab = _csr_parts(g)
 
+    halo = sliced == 'halo'
+    sliced = sliced is True
+
     def stack(world_):
         comms = e.Comm.loopback(world_)
         m = [e.Mlp(x['weights'], x['activations'], True) for x in (st0, ou0, st1, ou1)]
         bases, derived, l0, l1 = [], [], [], []
+        plan = e.halo_plan(n, world_, indptr, adj_src) if halo else None
         for r in range(world_):
             rb, nr, ip, src, w, aw, al_ = e.shard_csr(n, r, world_, indptr, adj_src, adj_w, arc_w, arc_lab)
-            bases.append(e.Graph(n, ip, src, w, aw, al_, g['nodes'], mask[rb:rb + nr], row_begin=rb))
+            if halo:
+                h = e.shard_halo(n, r, world_, indptr, adj_src, g['nodes'], plan)
+                bases.append(e.Graph.halo(n, r, world_, h['block'], h['send_rows'], ip, h['adj_src'], w, aw, al_, h['nodes'], mask[rb:rb + nr]))
+            else:
+                bases.append(e.Graph(n, ip, src, w, aw, al_, g['nodes'], mask[rb:rb + nr], row_begin=rb))
             l0.append(e.Loop(bases[-1], m[0], m[1], d, 20, 0.01, comms[r]))
             l0[-1].set_impl(1); l0[-1].set_state0(s0[rb:rb + nr])
+            if sliced and world_ > 1:
+                bases[-1].set_full_adjacency(n, indptr, adj_src, adj_w)
+                l0[-1].set_slice_exchange(True)
         k0 = e.Loop.run_group(l0)
         for r in range(world_):
             derived.append(bases[r].derive(d + 2))
         e.Graph.update_labels_group(derived, bases, l0, True, True)
-        labels = derived[0].nodes()
+        if halo:                                                       # index space [own rows | boundary blocks]: the own rows, in rank order
+            labels = np.concatenate([derived[r].nodes()[:e.shard_range(n, r, world_)[1]] for r in range(world_)])
+        else:
+            labels = derived[0].nodes()
         for r in range(world_):
-            assert np.array_equal(derived[r].nodes(), labels)          # every rank holds the same relabelled graph
+            if not halo: assert np.array_equal(derived[r].nodes(), labels)          # every rank holds the same relabelled graph
             l0[r].close()                                              # frees the rank's slot in the group
         for r in range(world_):
             rb, nr = e.shard_range(n, r, world_)
             l1.append(e.Loop(derived[r], m[2], m[3], d, 20, 0.01, comms[r]))
             l1[-1].set_impl(1); l1[-1].set_state0(s1[rb:rb + nr])
+            if sliced and world_ > 1: l1[-1].set_slice_exchange(True)
         k1 = e.Loop.run_group(l1)
         return k0, k1, labels, np.concatenate([lp.state() for lp in l1]), np.concatenate([lp.output() for lp in l1])
 
@@ -227,6 +245,42 @@ def test_sharded_lgnn_relabelling(world):
     assert (k0, k1) == (ka, kb)
     assert np.array_equal(labels, dg.nodes())
     assert np.array_equal(state, b.state()) and np.array_equal(out, b.output())
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_edge_based_readout(world):
+    """GNNedgeBased.apply_filters + net_output (reference GNN.py:289-302, :279) on node-range shards: a rank reads out the masked arcs of
+    its own CSR rows (destination owned, source anywhere in its replica); the per-rank outputs in rank order are the unsharded output."""
+    e = _engine()
+    rng = np.random.default_rng(70 + world)
+    n, d, nl, al = 500, 6, 3, 1
+    g, st, _, s0 = _case(33 + world, n, d)
+    ou = make_mlp(rng, 2 * (d + nl) + al, [5, 2], 'tanh', out_activation='softmax', bn_random=True)      # per-arc readout: [F(dst) | F(src) | arc label]
+    indptr, adj_src, adj_w, arc_w, arc_lab = _csr_parts(g)
+    E = len(adj_src)
+    entry_dst = np.repeat(np.arange(n, dtype=np.int32), np.diff(indptr))
+    arc_labels = (2 * rng.random((E, al)) - 1).astype(np.float32)        # labels paired with the entries by position (GNN.py:294-299)
+    arc_mask = rng.random(E) < 0.6
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+
+    def run(world_):
+        comms = e.Comm.loopback(world_)
+        loops, outs = [], []
+        for r in range(world_):
+            rb, nr, ip, src, w, aw, al_ = e.shard_csr(n, r, world_, indptr, adj_src, adj_w, arc_w, arc_lab)
+            e0, e1 = int(indptr[rb]), int(indptr[rb + nr])
+            gr = e.Graph(n, ip, src, w, aw, al_, g['nodes'], np.ones(nr, np.uint8), row_begin=rb)
+            lp = e.Loop(gr, mst, mou, d, 15, 0.01, comms[r])
+            lp.set_impl(1); lp.set_state0(s0[rb:rb + nr])
+            lp.set_edge_readout(entry_dst[e0:e1] - rb, arc_labels[e0:e1], arc_mask[e0:e1])
+            loops.append(lp)
+        k = e.Loop.run_group(loops)
+        return k, np.concatenate([lp.state() for lp in loops]), np.concatenate([lp.output() for lp in loops])
+
+    k1, s1, o1 = run(1)
+    kw, sw, ow = run(world)
+    assert o1.shape == (int(arc_mask.sum()), 2)
+    assert kw == k1 and np.array_equal(sw, s1) and np.array_equal(ow, o1)
 
 
 def test_loopback_group_errors():

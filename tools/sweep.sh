@@ -1,10 +1,12 @@
 #!/bin/bash
-# tuning sweep of the fused kernel on the GPU box (DIAG build): one bench line per setting, kernel ms and roofline fraction
+# tuning sweep of the fused kernel on the GPU box (diagnostic build: make -C gnn_tf_2.x_amd/csrc DIAG=1, loaded through GNN_HIP_LIBRARY):
+# one bench line per setting, kernel ms and roofline fraction
+export GNN_HIP_LIBRARY=${GNN_HIP_LIBRARY:-$PWD/gnn_tf_2.x_amd/GNN/libgnn_hip_diag.so}
 OUT=gpurun_out/sweep_${1:-x}.txt
 : > $OUT
 run() {
   echo "== $*" >> $OUT
-  env "$@" python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>>$OUT | python3 -c "
+  env "$@" python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs 2>>$OUT | python3 -c "
 import json,sys
 for l in sys.stdin:
     try: j=json.loads(l)
