@@ -671,15 +671,19 @@ __global__ void __launch_bounds__(64 * TG_WAVES, 2) k_gemm_f32(const GemmArgs p)
 // The same product in the split arithmetic of the fused inference kernel (gnn_fused_kernel.h: every fp32 operand cut into three exact
 // bf16 pieces, six piece products per term on v_mfma_f32_32x32x16_bf16, fp32 accumulation): 2.7 x fewer matrix-pipe cycles than the f32
 // MFMA, and the bf16 MFMA overlaps the wave's VALU work.  Packed operand: [K = 16 chunk][out tile][piece][lane][8 bf16] + two zero chunks.
-__global__ void k_pack_split(int K, int n_cols, int col0, int NO, int chunks_img, const float *__restrict__ M, uint32_t *__restrict__ out)
+// hidden: the k order of a layer whose input is the previous layer's accumulators (gnn_fused_kernel.h: chunk c, element i of k half h is
+// feature 32 (c >> 1) + (r & 3) + 8 (r >> 2) + 4 h, r = 8 (c & 1) + i); fold: factor on every weight (the folded SELU of the fused chain)
+__global__ void k_pack_split(int K, int n_cols, int col0, int NO, int chunks_img, const float *__restrict__ M, uint32_t *__restrict__ out, int hidden = 0,
+                             float fold = 1.0f)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;                 // one thread per (chunk, tile, lane, element pair): three dwords (pieces)
     if (t >= chunks_img * NO * 64 * 4) return;
     const int j2 = t & 3, lane = (t >> 2) & 63, jt = (t >> 8) % NO, c = (t >> 8) / NO;
     uint32_t d[3] = {0u, 0u, 0u};
     for (int e = 0; e < 2; ++e) {
-        const int i = 2 * j2 + e, k = 16 * c + 8 * (lane >> 5) + i, col = col0 + 32 * jt + (lane & 31);
-        float v = (k < K && col < n_cols) ? M[(size_t)k * n_cols + col] : 0.0f;
+        const int i = 2 * j2 + e, h = lane >> 5, r = 8 * (c & 1) + i, col = col0 + 32 * jt + (lane & 31);
+        const int k = hidden ? 32 * (c >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h : 16 * c + 8 * h + i;
+        float v = (k < K && col < n_cols) ? M[(size_t)k * n_cols + col] * fold : 0.0f;
         for (int pc = 0; pc < 3; ++pc) {                                 // truncation split: v == p0 + p1 + p2 exactly
             const uint32_t hi = __float_as_uint(v) & 0xffff0000u;
             v = v - __uint_as_float(hi);
@@ -813,6 +817,127 @@ __global__ void __launch_bounds__(64 * TG_WAVES, 2) k_gemm_split(const GemmArgs 
     }
 }
 
+// The three Dense layers of a 3-layer net_state in ONE pass over the rows (round 3): the chain of the fused inference kernel - layer 0 from
+// the LDS tile, the hidden layers from the previous accumulators without leaving registers (layer_split_from_regs, folded SELU) - with
+// the activations the backward pass differentiates written out on the way (a0, a1 after the layer that consumes them has cut them into
+// pieces, a2 at the end), each through the wave's LDS tile as whole row pieces.  Saves re-reading a0 and a1 (2 x 512 MB at 1 M rows) and
+// two stagings.  Shape: hidden width <= 128 (four 32-feature tiles), last width <= 64 (two).
+struct Fwd3Args {
+    int64_t n;
+    int K, KP, chunks0, w1, w2, w3, act;
+    int img_bytes, off1, off2;               // one packed image for the three layers: byte offsets of layers 1 and 2
+    const float *X, *b0, *b1, *b2;
+    const uint32_t *img;
+    float *A0, *A1, *A2;
+};
+
+template <int ACT>
+__global__ void __launch_bounds__(64 * TG_WAVES, 2) k_fwd3_split(const Fwd3Args p)
+{
+    using namespace gnn_fused_dev;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr bool FOLD = ACT == GNN_ACT_SELU;
+    constexpr float LOG2E = 1.44269504088896341f, UNFOLD = FOLD ? 1.0507009873554805f / LOG2E : 1.0f;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = p.K, KP = p.KP;
+    float *X = lds + (size_t)wave * 32 * KP;
+    float *hb = lds + (size_t)TG_WAVES * 32 * KP + 32;                   // biases: layer 0 [128] | layer 1 [128] | layer 2 [64]
+    for (int t = threadIdx.x; t < 320; t += blockDim.x) {
+        float v = 0.0f;
+        if (t < 128) v = t < p.w1 ? p.b0[t] * (FOLD ? LOG2E : 1.0f) : 0.0f;
+        else if (t < 256) v = t - 128 < p.w2 ? p.b1[t - 128] * (FOLD ? LOG2E : 1.0f) : 0.0f;
+        else v = t - 256 < p.w3 ? p.b2[t - 256] : 0.0f;
+        hb[t] = v;
+    }
+    __syncthreads();
+    const int64_t n_tiles = (p.n + 31) / 32, stride = (int64_t)gridDim.x * TG_WAVES;
+    const float inv_k = 1.0f / (float)K;
+    const int half = lane >> 5, node = lane & 31;
+    const bool kvec = (K & 3) == 0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.img), 0, p.img_bytes, 0x00020000);
+    // rows of one activation array through the LDS tile: accumulator layout -> [row][column] -> whole row pieces to memory
+    auto store_rows = [&](auto &h, auto NTc, float *dst, int width, int nvalid, int64_t i0, float scale, bool activate) {
+        constexpr int NTT = decltype(NTc)::value;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int half_o = half;
+        asm volatile("" : "+v"(half_o));
+#pragma unroll
+        for (int jt = 0; jt < NTT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4f v = {h[jt][4 * q], h[jt][4 * q + 1], h[jt][4 * q + 2], h[jt][4 * q + 3]};
+                if (activate) v = v4f{act_fast<ACT>(v.x), act_fast<ACT>(v.y), act_fast<ACT>(v.z), act_fast<ACT>(v.w)};
+                *reinterpret_cast<v4f *>(X + node * KP + 32 * jt + 8 * q + 4 * half_o) = v * scale;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        constexpr int PPR = 8 * NTT;
+        const bool vec = (width & 3) == 0;
+        int lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+#pragma unroll
+        for (int u = 0; u < 32 * PPR / 64; ++u) {
+            const int idx = lane_p + 64 * u, r = idx / PPR, c = (idx % PPR) * 4;
+            if (r < nvalid && c < width) {
+                const v4f a4 = *reinterpret_cast<const v4f *>(X + r * KP + c);
+                const int64_t o = (i0 + r) * width + c;
+                if (vec) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + o) = a4;
+                else {
+                    const float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                    for (int t = 0; t < 4; ++t) if (c + t < width) gptr_w(dst)[o + t] = v[t];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    v4f nxt[TG_MAXQ];
+    for (int64_t tile = (int64_t)blockIdx.x * TG_WAVES + wave; tile < n_tiles; tile += stride) {
+        const int64_t i0 = tile * 32;
+        const int nvalid = (int)((p.n - i0) < 32 ? (p.n - i0) : 32);
+        const int total = nvalid * K;
+        const float *src = p.X + i0 * K;
+#pragma unroll
+        for (int q = 0; q < TG_MAXQ; ++q) {
+            const int e = lane * 4 + 256 * q;
+            nxt[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (e + 4 <= total) nxt[q] = gload4(src + e);
+            else if (e < total) {
+                float t4[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < 4; ++u) if (e + u < total) t4[u] = gload1(src + e + u);
+                nxt[q] = v4f{t4[0], t4[1], t4[2], t4[3]};
+            }
+        }
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        // (the stores of the previous tile left values in columns [K, KP) of the tile region: zero them again - 0 x Inf would poison the sums)
+        for (int t = lane_o; t < 32 * (KP - K); t += 64) X[(t / (KP - K)) * KP + K + t % (KP - K)] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < TG_MAXQ; ++q) {
+            const int e = lane_o * 4 + 256 * q;
+            if (e < 32 * K) {
+                if (kvec) {
+                    const int r = (int)(((float)e + 0.5f) * inv_k), c = e - r * K;
+                    *reinterpret_cast<v4f *>(X + r * KP + c) = nxt[q];
+                } else {
+                    const float v[4] = {nxt[q].x, nxt[q].y, nxt[q].z, nxt[q].w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ee = e + u, r = (int)(((float)ee + 0.5f) * inv_k), c = ee - r * K;
+                        X[r * KP + c] = v[u];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        f32x16 h1[4], h2[4], out[2];
+        layer0_split<4, true>(X + node * KP + 8 * half, wrs, lane * 16, 0, p.chunks0, h1, hb, half);
+        layer_split_from_regs<4, 4, ACT>(h1, hb + 128, half, h2, wrs, lane * 16, p.off1);       // h1 now holds the (folded) activations of layer 0
+        store_rows(h1, std::integral_constant<int, 4>{}, p.A0, p.w1, nvalid, i0, UNFOLD, false);
+        layer_split_from_regs<4, 2, ACT>(h2, hb + 256, half, out, wrs, lane * 16, p.off2);
+        store_rows(h2, std::integral_constant<int, 4>{}, p.A1, p.w2, nvalid, i0, UNFOLD, false);
+        store_rows(out, std::integral_constant<int, 2>{}, p.A2, p.w3, nvalid, i0, 1.0f, true);
+    }
+}
+
 // K-steps of the wide products: a multiple of 12 (layer_from_lds consumes groups of 3 x 4) plus its look-ahead of 8
 inline int tg_kk(int K) { return ((K + 1) / 2 + 11) / 12 * 12; }
 inline int tg_kp(int K) { return std::max(2 * tg_kk(K), (K + 15) / 16 * 16) + 1; }
@@ -886,6 +1011,57 @@ int launch_gemm_f32(hipStream_t st, BufT &buf, int64_t n, int K, int n_cols, con
         HIPCHK(hipGetLastError());
         col0 += 32 * NO;
     }
+    return GNN_OK;
+}
+
+inline bool fwd3_covers(const gnn_mlp *m)
+{
+    if (m->n_layers != 3) return false;
+    const int a = m->acts[0];
+    if (a == GNN_ACT_SOFTMAX || m->acts[1] != a || m->acts[2] != a) return false;
+    return m->dims[0] >= 64 && m->dims[0] <= 144 && m->dims[1] > 64 && m->dims[1] <= 128 && m->dims[2] > 64 && m->dims[2] <= 128 && m->dims[3] > 32 && m->dims[3] <= 64;
+}
+
+template <class BufT>
+int launch_fwd3(hipStream_t st, BufT &buf, const gnn_mlp *m, int64_t n, const float *x, float *a0, float *a1, float *a2)
+{
+    static bool raised = false;
+    const void *ks[6] = {reinterpret_cast<const void *>(&k_fwd3_split<GNN_ACT_LINEAR>), reinterpret_cast<const void *>(&k_fwd3_split<GNN_ACT_RELU>),
+                         reinterpret_cast<const void *>(&k_fwd3_split<GNN_ACT_SELU>), reinterpret_cast<const void *>(&k_fwd3_split<GNN_ACT_ELU>),
+                         reinterpret_cast<const void *>(&k_fwd3_split<GNN_ACT_TANH>), reinterpret_cast<const void *>(&k_fwd3_split<GNN_ACT_SIGMOID>)};
+    if (!raised) {
+        for (const void *k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    Fwd3Args p{};
+    p.n = n; p.K = m->dims[0]; p.w1 = m->dims[1]; p.w2 = m->dims[2]; p.w3 = m->dims[3]; p.act = m->acts[0];
+    p.KP = std::max(tg_kps(p.K), tg_kps(128));
+    p.chunks0 = (p.K + 15) / 16;
+    const size_t blk = 3 * 256;                                          // dwords per (chunk, tile)
+    const size_t d0 = (size_t)(p.chunks0 + 2) * 4 * blk, d1 = (size_t)8 * 4 * blk, d2 = (size_t)8 * 2 * blk;
+    uint32_t *img = nullptr;
+    int rc = buf.get(&img, d0 + d1 + d2);
+    if (rc) return rc;
+    const bool fold = p.act == GNN_ACT_SELU;
+    const float LOG2E = 1.44269504088896341f, SCALE = 1.0507009873554805f;
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)(p.chunks0 + 2) * 4 * 256, 256), 256, 0, st, p.K, p.w1, 0, 4, p.chunks0 + 2, m->W[0], img, 0, fold ? LOG2E : 1.0f);
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)8 * 4 * 256, 256), 256, 0, st, p.w1, p.w2, 0, 4, 8, m->W[1], img + d0, 1, fold ? SCALE : 1.0f);
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)8 * 2 * 256, 256), 256, 0, st, p.w2, p.w3, 0, 2, 8, m->W[2], img + d0 + d1, 1, fold ? SCALE / LOG2E : 1.0f);
+    p.img = img; p.img_bytes = (int)((d0 + d1 + d2) * sizeof(uint32_t)); p.off1 = (int)(d0 * sizeof(uint32_t)); p.off2 = (int)((d0 + d1) * sizeof(uint32_t));
+    p.X = x; p.b0 = m->b[0]; p.b1 = m->b[1]; p.b2 = m->b[2]; p.A0 = a0; p.A1 = a1; p.A2 = a2;
+    const size_t lds = sizeof(float) * ((size_t)TG_WAVES * 32 * p.KP + 32 + 320) + 16;
+    if (lds > 160 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused forward: LDS");
+    const int64_t n_tiles = (n + 31) / 32;
+    const unsigned grid = (unsigned)std::min<int64_t>(256, (n_tiles + TG_WAVES - 1) / TG_WAVES);
+    switch (p.act) {
+    case GNN_ACT_LINEAR: hipLaunchKernelGGL((k_fwd3_split<GNN_ACT_LINEAR>), grid, 64 * TG_WAVES, lds, st, p); break;
+    case GNN_ACT_RELU: hipLaunchKernelGGL((k_fwd3_split<GNN_ACT_RELU>), grid, 64 * TG_WAVES, lds, st, p); break;
+    case GNN_ACT_SELU: hipLaunchKernelGGL((k_fwd3_split<GNN_ACT_SELU>), grid, 64 * TG_WAVES, lds, st, p); break;
+    case GNN_ACT_ELU: hipLaunchKernelGGL((k_fwd3_split<GNN_ACT_ELU>), grid, 64 * TG_WAVES, lds, st, p); break;
+    case GNN_ACT_TANH: hipLaunchKernelGGL((k_fwd3_split<GNN_ACT_TANH>), grid, 64 * TG_WAVES, lds, st, p); break;
+    default: hipLaunchKernelGGL((k_fwd3_split<GNN_ACT_SIGMOID>), grid, 64 * TG_WAVES, lds, st, p); break;
+    }
+    HIPCHK(hipGetLastError());
     return GNN_OK;
 }
 
@@ -1473,7 +1649,23 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
     float *h = x;
     size_t mask_off = 0;
     int rc;
-    for (int l = 0; l <= L; ++l) {
+    int l_start = 0;
+    // a 3-layer net without Dropout behind its first layer, on many rows: the three Dense layers in one pass (k_fwd3_split)
+    bool fuse3 = n > 0 && tg_many_rows(n) && fwd3_covers(m) && net.rate[1] == 0.0f && net.rate[2] == 0.0f && (net.rate[0] == 0.0f || keep0);
+#ifdef GNN_DIAG
+    static const bool fuse_off = getenv("GNN_TRAIN_FWD3") && atoi(getenv("GNN_TRAIN_FWD3")) == 0;
+    if (fuse_off) fuse3 = false;
+#endif
+    if (fuse3) {
+        if (net.rate[0] != 0.0f) { c.keep[0] = keep0; mask_off += (size_t)n * m->dims[0]; }
+        for (int l = 0; l < 3; ++l)
+            if ((rc = buf.get(&c.a[l], (size_t)n * m->dims[l + 1]))) return rc;
+        c.hin[0] = x; c.hin[1] = c.a[0]; c.hin[2] = c.a[1];
+        if ((rc = launch_fwd3(st, buf, m, n, x, c.a[0], c.a[1], c.a[2]))) return rc;
+        h = c.a[2];
+        l_start = L;
+    }
+    for (int l = l_start; l <= L; ++l) {
         const int width = m->dims[l];
         if (net.rate[l] != 0.0f) {
             if (l == 0 && keep0) c.keep[0] = keep0;

@@ -15,7 +15,8 @@ arcs = random_arcs(rng, n, 4 * n, al)
 nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
 g = orc.make_graph_dict(arcs, nodes, 'average')
 g['set_mask'] = rng.random(n) < 0.9
-st = make_mlp(rng, al + 2 * (d + nl), [128, 128, d], 'selu', gain=0.7, bn_random=True)
+ACT = os.environ.get('ACT', 'selu')
+st = make_mlp(rng, al + 2 * (d + nl), [128, 128, d], ACT, gain=0.7, bn_random=True)
 ou = make_mlp(rng, d + nl, [2], 'softmax', batch_normalization=False)
 st['dropout'], ou['dropout'] = {}, {}
 mask = g['set_mask'] & g['output_mask']
