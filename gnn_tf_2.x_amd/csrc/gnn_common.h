@@ -223,6 +223,8 @@ struct gnn_loop {
     int *kfinal_dev = nullptr, *kfinal_host = nullptr;   // device [4]: k, persistent-loop barrier counter, its status word, pad; host mirror [4]
     bool small_words_clean = false;         // the double-buffered gate words of the persistent loop are zero / in their run-parity state
     unsigned small_runs = 0;
+    float *small_xs = nullptr;              // the persistent loop's padded exchange rows (gnn_small.hip), allocated with its first run
+    size_t small_xs_floats = 0;
     bool small_disabled = false;            // the persistent small-graph loop gave up once on this loop: keep to per-body launches
     int kfinal = -1;
     bool have_state0 = false, ran = false;

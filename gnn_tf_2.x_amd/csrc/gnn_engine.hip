@@ -2140,6 +2140,7 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     for (int b = 0; b < 2; ++b) { (void)hipFree(l->state[b]); (void)hipFree(l->tmp[b]); (void)hipFree(l->otmp[b]); }
     (void)hipFree(l->inp); (void)hipFree(l->inv); (void)hipFree(l->state_init); (void)hipFree(l->feats); (void)hipFree(l->out); (void)hipFree(l->flags); (void)hipFree(l->kfinal_dev); (void)hipFree(l->tile_ctr);
     if (l->kfinal_host) (void)hipHostFree(l->kfinal_host);
+    (void)hipFree(l->small_xs);
     for (hipEvent_t e : l->ev) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) if (l->ev_total[i]) (void)hipEventDestroy(l->ev_total[i]);
     if (l->gate_host) (void)hipHostFree(l->gate_host);

@@ -58,8 +58,11 @@ struct GnnSmallCtl {
     const float *init;       // initial state of the owned rows [n_rows, Ds] (injected / drawn state, or the node labels for D == 0)
     int *kfinal;             // receives the number of executed bodies
     int *flags;              // word [b]: barrier + gate of body b (low half arrivals, high half movers), zeroed before the launch
-    int *status;             // = kfinal + 1: set to 1 by a workgroup whose barrier spin gave up; never cleared by the kernel (sticky), zeroed by the host before the launch
-    int *host_result;        // pinned host memory (zero-copy): [k, status] for the host, or nullptr; status as above: host clears, kernel only sets
+    int *host_result;        // pinned host memory (zero-copy): [k, status]; status: set to 1 by a workgroup whose barrier spin gave up, never cleared by the
+                             // kernel (sticky), zeroed by the host before the launch
+    float *xs;               // padded exchange rows [2][tiles * 32][DP] (gnn_small.hip, small_gather_padded): the state between bodies
+    int DP;                  // 16 (Ds <= 16) or 32 floats per exchange row
+    int rnd;                 // arcs per gather round for DP == 16 (4, or 8 when some row has more than 8 arcs)
     int *zero_words;         // the OTHER run's gate words (double-buffered by run parity): zeroed here for the next run
     int n_words;
     int max_iter;
@@ -78,7 +81,7 @@ struct GnnSmallCtl {
     int G, ro_word;
     int ecache;              // arcs of a tile whose ids / weights may be kept in LDS (GNN_SMALL_ECACHE; 0: none)
 };
-bool gnn_small_launch(int layers, int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
+bool gnn_small_launch(int layers, int act, int kk0, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
                       hipStream_t st);
 
 // one per translation unit gnn_fused_l{1,2,3}.hip; false = no instantiation for (act, nt, ntl)

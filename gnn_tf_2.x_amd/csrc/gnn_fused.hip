@@ -471,8 +471,19 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     c.state0 = l->state[0]; c.state1 = l->state[1];
     c.init = l->D ? l->state_init : g->nodes + (size_t)g->own_off * g->NL;      // D == 0: NL == Ds (GNN.py:265)
     c.kfinal = l->kfinal_dev;
-    c.status = l->kfinal_dev + 1;
     c.host_result = l->kfinal_host;                                   // pinned, device-visible: no copy back
+    const unsigned grid = (unsigned)((g->n_rows + 31) / 32);
+    c.DP = l->Ds <= 16 ? 16 : 32;
+    {   // padded exchange rows: allocated with the first persistent run of the loop, never initialised (every row is written before it is read)
+        const size_t need = (size_t)2 * grid * 32 * c.DP;
+        if (l->small_xs_floats < need) {
+            if (l->small_xs) (void)hipFree(l->small_xs);
+            l->small_xs = nullptr; l->small_xs_floats = 0;
+            HIPCHK(hipMalloc((void **)&l->small_xs, need * sizeof(float)));
+            l->small_xs_floats = need;
+        }
+        c.xs = l->small_xs;
+    }
     c.max_iter = l->max_iter;
     c.ecache = 1024;                                                  // = GNN_SMALL_ECACHE (gnn_small.hip)
 #ifdef GNN_DIAG
@@ -484,7 +495,6 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     // something else (a per-body run) has used the block.
     const size_t n_words = ((size_t)l->max_iter + 3 + 3) & ~(size_t)3;      // gate of every body, + 1, + the barrier in front of the folded graph readout
     l->kfinal_host[1] = 0;                                            // status: cleared HERE, only ever set by the kernel (sticky)
-    HIPCHK(hipMemsetAsync(l->kfinal_dev + 1, 0, sizeof(int), l->stream));
     if (!l->small_words_clean) {
         HIPCHK(hipMemsetAsync(l->flags, 0, sizeof(int) * 2 * n_words, l->stream));
         l->small_words_clean = true;
@@ -518,9 +528,13 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
             }
         }
     }
-    const unsigned grid = (unsigned)((g->n_rows + 31) / 32);
     const size_t lds = sizeof(float) * ((size_t)32 * p.KP + 32 + 36 + 160 + 544 + 2048 + 2 * 1024 + 4);    // tile, row pointers, epilogue vectors, head, scratch, arc cache (GNN_SMALL_ECACHE)
-    const int rnd = g->sh->max_degree > 8 ? 8 : 4;               // entries per gather round
+    c.rnd = g->sh->max_degree > 8 ? 8 : 4;                       // entries per gather round
+    // K-steps of layer 0 the kernel keeps in registers: the smallest instantiated count that covers the concat width (the packed
+    // image has p.kk0 >= that many; the steps dropped are zero rows of the image)
+    int kk_small = p.kk0;
+    for (int cand : {8, 12, 16, 24, 32, 36, 40, 48})
+        if (2 * cand >= a.in_s && cand <= p.kk0) { kk_small = cand; break; }
 #ifdef GNN_DIAG
     static const char *small_stamp_file = getenv("GNN_SMALL_STAMPS");
     static unsigned long long *small_stamp_buf = nullptr;
@@ -530,7 +544,7 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
         a.stamps = small_stamp_buf;
     }
 #endif
-    if (!gnn_small_launch(p.layers, p.act, p.kk0, rnd, a, c, grid, lds, l->stream))
+    if (!gnn_small_launch(p.layers, p.act, kk_small, a, c, grid, lds, l->stream))
         return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
     HIPCHK(hipGetLastError());
 #ifdef GNN_DIAG

@@ -137,6 +137,29 @@ __device__ __forceinline__ float act_t(float v)
     }
 }
 
+// act_t on a PAIR of elements with the arithmetic on packed float2 operands (v_pk_mul / add / fma_f32: two IEEE results per issue
+// slot, the same bits as the scalar instructions in the same order)
+template <int ACT>
+__device__ __forceinline__ v2f act_t2(v2f v)
+{
+    if constexpr (ACT == GNN_ACT_SELU) {
+        auto splat = [](float c) { return v2f{c, c}; };
+        const v2f u = v * splat(1.44269504088896341f);
+        const v2f n = v2f{__builtin_rintf(u.x), __builtin_rintf(u.y)};
+        const v2f f = u - n;
+        v2f p = __builtin_elementwise_fma(splat(0.0013218672247603536f), f, splat(0.009671698324382305f));
+        p = __builtin_elementwise_fma(p, f, splat(0.05550893023610115f));
+        p = __builtin_elementwise_fma(p, f, splat(0.24022237956523895f));
+        p = __builtin_elementwise_fma(p, f, splat(0.6931468844413757f));
+        p = __builtin_elementwise_fma(p, f, splat(1.0f));
+        v2f e = v2f{__builtin_ldexpf(p.x, (int)n.x), __builtin_ldexpf(p.y, (int)n.y)};
+        e = splat(1.6732632423543772f) * (e - splat(1.0f));
+        return splat(1.0507009873554805f) * v2f{v.x > 0.0f ? v.x : e.x, v.y > 0.0f ? v.y : e.y};
+    } else {
+        return v2f{act_t<ACT>(v.x), act_t<ACT>(v.y)};
+    }
+}
+
 // Activations of the split-arithmetic path (tolerance-based parity, so the hardware transcendentals are admissible):
 // v_exp_f32 / v_rcp_f32 are accurate to 1 ulp; the formulas are those of gnn_act.
 template <int ACT>
@@ -163,12 +186,14 @@ __device__ __forceinline__ float act_fast(float v)
 // 32 jt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 // LDS: the three vectors were staged in LDS at kernel start (last layer of the tile loop: no global round trips per tile)
 // NOBIAS: the accumulator was started from the bias (split arithmetic, bias_tile)
+// fmax: features >= fmax are padding of the tile (never stored): groups of registers that hold only such features are skipped
 template <int ACT, bool BN, bool FAST = false, bool LDS = false, bool NOBIAS = false>
 __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, const float *bn_scale, const float *bn_shift,
-                                              int jt, int half)
+                                              int jt, int half, int fmax = 1 << 30)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (32 * jt + 8 * q >= fmax) continue;           // (wave-uniform)
         const int f0 = 32 * jt + 8 * q + 4 * half;
         v4f b = {0.f, 0.f, 0.f, 0.f};
         if constexpr (!NOBIAS) b = LDS ? *reinterpret_cast<const v4f *>(bias + f0) : gload4(bias + f0);
@@ -180,12 +205,24 @@ __device__ __forceinline__ void tile_epilogue(f32x16 &a, const float *bias, cons
             sc[0] = s4.x; sc[1] = s4.y; sc[2] = s4.z; sc[3] = s4.w;
             sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
         }
+        if constexpr (FAST) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = NOBIAS ? a[4 * q + t] : a[4 * q + t] + bb[t];
-            v = FAST ? act_fast<ACT>(v) : act_t<ACT>(v);
-            if (BN) { const float m = v * sc[t]; v = m + sh[t]; }
-            a[4 * q + t] = v;
+            for (int t = 0; t < 4; ++t) {
+                float v = NOBIAS ? a[4 * q + t] : a[4 * q + t] + bb[t];
+                v = act_fast<ACT>(v);
+                if (BN) { const float m = v * sc[t]; v = m + sh[t]; }
+                a[4 * q + t] = v;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {             // pairs: packed arithmetic, the same bits
+                v2f v = v2f{a[4 * q + t], a[4 * q + t + 1]};
+                if constexpr (!NOBIAS) v = v + v2f{bb[t], bb[t + 1]};
+                v = act_t2<ACT>(v);
+                if (BN) { const v2f m = v * v2f{sc[t], sc[t + 1]}; v = m + v2f{sh[t], sh[t + 1]}; }
+                a[4 * q + t] = v.x;
+                a[4 * q + t + 1] = v.y;
+            }
         }
     }
 }
@@ -611,7 +648,7 @@ __device__ __forceinline__ void zero_pad_columns(const GnnFusedArgs &a, float *X
 template <bool COH = false, int RND = 4>
 __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *X, const int *ipt, int64_t i0, int lane,
                                                int nvalid, int KP, int c_aggs, bool own_from_lds = false, const int *ecache_src = nullptr,
-                                               const float *ecache_w = nullptr, int ecache_base = 0)
+                                               const float *ecache_w = nullptr, int ecache_base = 0, bool skip_gather = false)
 {
     const int Ds = a.Ds, NLc = a.NLc;
     if (!own_from_lds) {
@@ -639,6 +676,7 @@ __device__ __forceinline__ void load_tile_generic(const GnnFusedArgs &a, float *
         for (int t = lane; t < total; t += 64, rc.next()) X[rc.i * KP + label_col(rc.c, Ds, NLc, c_aggs)] = gload1(src + t);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (skip_gather) return;       // k_small_loop: the aggregate comes from the padded exchange rows (small_gather_padded)
     if (a.agg_in) {        // feature-sliced exchange: the aggregate of the owned rows was computed outside (contiguous rows, no gather)
         const float *src = a.agg_in + i0 * Ds;
         const int total = nvalid * Ds;
@@ -950,13 +988,13 @@ __device__ __forceinline__ void load_tile_given64(const GnnFusedArgs &a, float *
 // condition() for the next body + coalesced store of the new rows.  New state sits in columns [c_aggs, c_aggs + Ds).
 // lanes 0..31 sum (new - old)^2, lanes 32..63 sum old^2, ascending feature order, unfused (oracle order).
 // moved_out != nullptr: the verdict "some node of the tile still moves" is returned there instead of raised in a.flag_out
-template <bool COH = false>
+// STORE == false: the condition only (k_small_loop stores the rows itself, into its padded exchange buffer)
+template <bool COH = false, bool STORE = true>
 __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float *X, int64_t i0, int lane, int nvalid, int KP,
                                                  int c_aggs, int *moved_out = nullptr)
 {
     const int Ds = a.Ds, half = lane >> 5;
-    {   // the row stores first: they drain (write-through in the persistent loop, which waits for them before its barrier) while the
-        // condition is evaluated
+    if constexpr (STORE) {   // the row stores first: they drain while the condition is evaluated
         float *dst = a.state_nxt + i0 * Ds;
         const int total = nvalid * Ds;
         RowCol rc(lane, Ds);

@@ -18,6 +18,7 @@
 
 namespace gnn_fused_dev {
 
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr int GNN_SMALL_ECACHE = 1024;             // arcs of a tile whose ids / weights are kept in LDS (8 KB)
 
 // Dense layers with the packed A operands (gnn_fused_pack, exact image: [K-step][lane][tile]) held in REGISTERS for the whole
@@ -45,8 +46,80 @@ __device__ __forceinline__ void small_layer(f32x16 &hin, const float *bias_prev,
     }
 }
 
-// KK0: K-steps of layer 0 (a multiple of 12, gnn_fused.hip make_plan); RND: entries per gather round
-template <int LAYERS, int ACT, int KK0, int RND>
+
+// ---- padded exchange rows ------------------------------------------------------------------------------------------------------
+// Between bodies the state travels through a buffer of its own, xs[2][tiles * 32][DP] with DP = 16 or 32 floats per row (a
+// 64- or 128-byte line piece per node), not through the [N, Ds] state replicas: a tile publishes its 32 new rows as ONE contiguous
+// block of 16-byte write-through stores (2 or 4 store instructions instead of Ds scalar ones - a 4-byte sc1 store is a fabric write of
+// its own, MI355X_MICROARCH.md "stores of each flavour") and a neighbour row is fetched with 16-byte sc1 loads (2 per lane and arc for
+// Ds <= 16 instead of Ds / 2 scalar ones).  The [N, Ds] replicas get the initial and the final state only.
+// HW: floats per half-wave lane (DP / 2); PR: arcs per round.  The fmaf chain per column runs over the arcs in stored order, as before.
+template <int HW, int PR>
+__device__ __forceinline__ void small_gather_padded(__amdgpu_buffer_rsrc_t rs, float *X, const int *ipt, int lane, int nvalid, int KP, int c_aggs,
+                                                    int Ds, const int *adj_src, const float *adj_w, const int *ec_src, const float *ec_w, int ec_base)
+{
+    const int node = lane & 31, hf = lane >> 5;
+    const int beg = ipt[node], end = ipt[node + 1];
+    float acc[HW];
+#pragma unroll
+    for (int c = 0; c < HW; ++c) acc[c] = 0.0f;
+    for (int e = beg; e < end; e += PR) {
+        float w[PR];
+        int off[PR];
+#pragma unroll
+        for (int u = 0; u < PR; ++u) {
+            const int ee = e + u < end ? e + u : e;            // clamp: a real entry, result unused
+            w[u] = ec_w ? ec_w[ee - ec_base] : gload1(adj_w + ee);
+            const int src = ec_src ? ec_src[ee - ec_base] : gload1(adj_src + ee);
+            off[u] = (src * (2 * HW) + hf * HW) * 4;
+        }
+        v4f x[PR][HW / 4];
+#pragma unroll
+        for (int u = 0; u < PR; ++u)
+#pragma unroll
+            for (int j = 0; j < HW / 4; ++j) x[u][j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, off[u] + 16 * j, 0, 16));    // aux 16 = sc1
+#pragma unroll
+        for (int u = 0; u < PR; ++u)
+            if (e + u < end) {
+#pragma unroll
+                for (int j = 0; j < HW / 4; ++j) {
+                    acc[4 * j] = __builtin_fmaf(w[u], x[u][j].x, acc[4 * j]);
+                    acc[4 * j + 1] = __builtin_fmaf(w[u], x[u][j].y, acc[4 * j + 1]);
+                    acc[4 * j + 2] = __builtin_fmaf(w[u], x[u][j].z, acc[4 * j + 2]);
+                    acc[4 * j + 3] = __builtin_fmaf(w[u], x[u][j].w, acc[4 * j + 3]);
+                }
+            }
+    }
+    if (node < nvalid) {
+        float *x = X + node * KP + c_aggs + hf * HW;
+#pragma unroll
+        for (int c = 0; c < HW; ++c)
+            if (hf * HW + c < Ds) x[c] = acc[c];
+    }
+}
+
+// the tile's 32 rows -> its block of the padded buffer.  Source element (row, col) at src[row * rs_ + col]; rows >= nrows and columns
+// >= Ds are stored as zeros (never read back into a result: a gather only keeps columns < Ds of rows that exist)
+template <int DP>
+__device__ __forceinline__ void small_store_padded(__amdgpu_buffer_rsrc_t rs, int64_t i0, const float *src, int rs_, int nrows, int Ds, int lane)
+{
+    constexpr int QR = DP / 4;                       // 16-byte pieces per row
+#pragma unroll
+    for (int u = 0; u < (32 * QR) / 64; ++u) {
+        const int q = lane + 64 * u, row = q / QR, c4 = (q % QR) * 4;
+        const float *x = src + row * rs_ + c4;
+        const bool rok = row < nrows;
+        v4f v;
+        v.x = (rok && c4 < Ds) ? x[0] : 0.0f;
+        v.y = (rok && c4 + 1 < Ds) ? x[1] : 0.0f;
+        v.z = (rok && c4 + 2 < Ds) ? x[2] : 0.0f;
+        v.w = (rok && c4 + 3 < Ds) ? x[3] : 0.0f;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), rs, (int)(i0 * DP + 4 * q) * 4, 0, 16);       // aux 16 = sc1: write-through
+    }
+}
+
+// KK0: K-steps of layer 0 kept in registers (a multiple of 8 that covers the concat width); RND: arcs per gather round for rows of <= 16 floats
+template <int LAYERS, int ACT, int KK0>
 __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const GnnSmallCtl c)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -97,8 +170,31 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     }
     const int64_t i0 = (int64_t)blockIdx.x * 32;
     const int nvalid = (int)((a0.n_rows - i0) < 32 ? (a0.n_rows - i0) : 32);
-    {   // the tile's row pointers: read once, kept in LDS for every body
-        const int my_ip = (lane <= nvalid) ? gload1(a0.indptr + i0 + lane) : 0;
+    // Everything the launch reads from read-only memory is requested HERE, at once (one round trip for all of it): row pointers, the
+    // tile's initial rows, and what the output stage needs at the very end (label rows, mask, output position)
+    const int my_ip = (lane <= nvalid) ? gload1(a0.indptr + i0 + lane) : 0;
+    const int Ds0 = a0.Ds;
+    float v_init[16];
+    {
+        const float *init = c.init + i0 * Ds0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v_init[u] = (lane + 64 * u < nvalid * Ds0) ? gload1(init + lane + 64 * u) : 0.0f;
+    }
+    bool out_on = false;
+    int out_pos = 0;
+    if (c.out) {
+        const int nl = c.NLc ? nvalid * c.NL : 0;                   // <= 1024 (NL <= 32)
+        const float *nod = c.nodes_own + i0 * c.NL;
+        float lv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lv[u] = (lane + 64 * u < nl) ? gload1(nod + lane + 64 * u) : 0.0f;
+        out_on = lane < nvalid && c.mask[i0 + (lane < nvalid ? lane : 0)];
+        out_pos = out_on ? c.mask_pos[i0 + lane] : 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (lane + 64 * u < nl) scr[1024 + lane + 64 * u] = lv[u];      // (scr is not touched again before the output stage)
+    }
+    {   // the tile's row pointers: kept in LDS for every body
         const int last_ip = shfl_i(my_ip, nvalid);
         if (lane <= 32) ipt[lane] = lane <= nvalid ? my_ip : last_ip;
     }
@@ -127,6 +223,10 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     SMALL_STAMP();                                                   // 1: set-up loads issued (weights, row pointers)
     const unsigned n_wg = gridDim.x;
+    // the two padded exchange buffers (see small_gather_padded), as buffer resources: 16-byte sc1 loads / stores
+    const int xs_bytes = (int)gridDim.x * 32 * c.DP * 4;
+    const __amdgpu_buffer_rsrc_t xs_rs[2] = {__builtin_amdgcn_make_buffer_rsrc(c.xs, 0, xs_bytes, 0x00020000),
+                                             __builtin_amdgcn_make_buffer_rsrc(c.xs + (size_t)gridDim.x * 32 * c.DP, 0, xs_bytes, 0x00020000)};
     // Grid barrier + gate in ONE word per body: after its write-through stores have drained, every workgroup adds
     // 1 (+ 0x10000 when one of its nodes still moves) to word[b]; the word is complete when its low half reaches the number of
     // workgroups, and body b runs iff its high half is non-zero (GNN.py:218-220: reduce_any over all nodes).  One atomic and one
@@ -146,13 +246,10 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         }
         seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
         if (seen == 0xffffffffu) {
-            // STICKY failure: the kernel only ever SETS the status words (the host clears them before the launch, gnn_small_run).  A
+            // STICKY failure: the kernel only ever SETS the status word (pinned host memory; the host clears it before the launch, gnn_small_run).  A
             // workgroup that gives up has already added itself to the barrier word, so a late arrival can still complete that barrier
             // for the others; if it is the last one they finish normally - and must not overwrite this 1 with a 0.
-            if (lane == 0) {
-                __hip_atomic_store((GNN_GLOBAL int *)c.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c.host_result) c.host_result[1] = 1;
-            }
+            if (lane == 0) c.host_result[1] = 1;
             return -1;
         }
         return (seen >> 16) ? 1 : 0;
@@ -161,16 +258,14 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     // oracle's order (k_check: ascending feature, unfused, one lane per row) ----------------------------------------------------
     int go;
     {
-        const float *init = c.init + i0 * Ds;
         float *own0 = c.state0 + (a0.row_begin + i0) * Ds;
-        const int total = nvalid * Ds;                          // <= 32 x 32: sixteen loads per lane at most, all in flight at once
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = (lane + 64 * u < total) ? gload1(init + lane + 64 * u) : 0.0f;
+        const int total = nvalid * Ds;                          // <= 32 x 32: sixteen values per lane at most (requested at kernel start)
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (lane + 64 * u < total) { sstore1<true>(own0 + lane + 64 * u, v[u]); X[lane + 64 * u] = v[u]; }
+            if (lane + 64 * u < total) { *gptr_w(own0 + lane + 64 * u) = v_init[u]; X[lane + 64 * u] = v_init[u]; }      // replica 0: read by nobody in this launch (k == 0: the final state)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (c.DP == 16) small_store_padded<16>(xs_rs[0], i0, X, Ds, nvalid, Ds, lane);      // what body 0 gathers from, behind gate 0
+        else small_store_padded<32>(xs_rs[0], i0, X, Ds, nvalid, Ds, lane);
         int moved = 0;
         if (lane < nvalid) {
             float dist = 0.0f, nrm = 0.0f;
@@ -190,10 +285,17 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
     int k = 0;
     for (; k < c.max_iter && go == 1; ++k) {
         GnnFusedArgs a = a0;
-        // body 0 gathers from the read-only initial state (no tile has to wait for the others' copies of it)
-        a.state_cur = k == 0 ? c.init - a0.row_begin * Ds : ((k & 1) ? c.state1 : c.state0);
-        a.state_nxt = ((k & 1) ? c.state0 : c.state1) + a0.row_begin * Ds;
-        load_tile_generic<true, RND>(a, X, ipt, i0, lane, nvalid, KP, c_aggs, k > 0, ecached ? ec_src : nullptr, ecached ? ec_w : nullptr, e_base);     // k > 0: the tile skeleton is still in LDS
+        a.state_cur = c.init - a0.row_begin * Ds;                    // (body 0 builds the tile skeleton: own rows from the read-only initial state)
+        a.state_nxt = nullptr;
+        load_tile_generic<false, 4>(a, X, ipt, i0, lane, nvalid, KP, c_aggs, k > 0, nullptr, nullptr, 0, true);     // k > 0: the tile skeleton is still in LDS; no gather here
+        {
+            const __amdgpu_buffer_rsrc_t rs = xs_rs[k & 1];
+            const int *es = ecached ? ec_src : nullptr;
+            const float *ew = ecached ? ec_w : nullptr;
+            if (c.DP == 32) small_gather_padded<16, 4>(rs, X, ipt, lane, nvalid, KP, c_aggs, Ds, a0.adj_src, a0.adj_w, es, ew, e_base);
+            else if (c.rnd == 8) small_gather_padded<8, 8>(rs, X, ipt, lane, nvalid, KP, c_aggs, Ds, a0.adj_src, a0.adj_w, es, ew, e_base);
+            else small_gather_padded<8, 4>(rs, X, ipt, lane, nvalid, KP, c_aggs, Ds, a0.adj_src, a0.adj_w, es, ew, e_base);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         SMALL_STAMP();                                               // body + 0: tile loaded (gather)
         const float *xb = X + (lane & 31) * KP + half;
@@ -215,8 +317,8 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (a.bn_scale) tile_epilogue<ACT, true, false, true>(out, ep, ep + 32, ep + 64, 0, half);
-        else tile_epilogue<ACT, false, false, true>(out, ep, nullptr, nullptr, 0, half);
+        if (a.bn_scale) tile_epilogue<ACT, true, false, true>(out, ep, ep + 32, ep + 64, 0, half, Ds);      // features >= Ds: padding of the tile
+        else tile_epilogue<ACT, false, false, true>(out, ep, nullptr, nullptr, 0, half, Ds);
         {
             float *x = X + (lane & 31) * KP + c_aggs;
 #pragma unroll
@@ -228,40 +330,41 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         SMALL_STAMP();                                               // body + 1: dense layers, new state in LDS
         int moved = 0;
-        check_store_generic<true>(a, X, i0, lane, nvalid, KP, c_aggs, &moved);
+        // the new rows first (they drain while the condition is evaluated), then the condition
+        if (c.DP == 16) small_store_padded<16>(xs_rs[(k & 1) ^ 1], i0, X + c_aggs, KP, 32, Ds, lane);
+        else small_store_padded<32>(xs_rs[(k & 1) ^ 1], i0, X + c_aggs, KP, 32, Ds, lane);
+        check_store_generic<false, false>(a, X, i0, lane, nvalid, KP, c_aggs, &moved);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         SMALL_STAMP();                                               // body + 2: condition, row stores drained
         go = arrive_and_gate(k + 1, moved);
         SMALL_STAMP();                                               // body + 3: barrier + gate
     }
     if (go < 0) return;                      // (status words already set, see arrive_and_gate; this tile's output rows stay stale: the host repeats the Loop)
+    // the final state of the tile's rows into the [N, Ds] replica the host expects it in (k & 1); k == 0: replica 0 holds it already
+    if (k > 0) {
+        float *dst = ((k & 1) ? c.state1 : c.state0) + (a0.row_begin + i0) * Ds;
+        const int total = nvalid * Ds;
+        RowCol rc(lane, Ds);
+        for (int t = lane; t < total; t += 64, rc.next()) *gptr_w(dst + t) = X[rc.i * KP + c_aggs + rc.c];
+    }
     if (blockIdx.x == 0 && lane == 0) {      // executed bodies (GNN.py:267; every workgroup agrees).  The status words are NOT touched here.
         c.kfinal[0] = k;
-        if (c.host_result) c.host_result[0] = k;
+        c.host_result[0] = k;
     }
     // ---- apply_filters + one-layer net_output on the tile's masked rows (GNN.py:275-279), arithmetic as k_out1: k-ordered fmaf
     // chain per output, bias, softmax / activation, BatchNormalization ------------------------------------------------------
     // The tile's final state rows (its own write-through stores) and label rows are contiguous in memory: all lanes copy them into
     // LDS with every load in flight at once (one round trip, not one per k-step); the head's weights were staged at kernel start.
     if (c.out) {
-        const int wf = Ds + c.NLc, T = c.T, NL = c.NL, NLc = c.NLc;
-        const float *sfin = ((k & 1) ? c.state1 : c.state0) + (a0.row_begin + i0) * Ds;
-        const float *nod = c.nodes_own + i0 * NL;
-        const int ns = nvalid * Ds, nl = NLc ? nvalid * NL : 0;          // <= 1024 each (Ds, NL <= 32)
-        float sv[16], lv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            sv[u] = (lane + 64 * u < ns) ? sload1<true>(sfin + lane + 64 * u) : 0.0f;
-            lv[u] = (lane + 64 * u < nl) ? gload1(nod + lane + 64 * u) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (lane + 64 * u < ns) scr[lane + 64 * u] = sv[u];
-            if (lane + 64 * u < nl) scr[1024 + lane + 64 * u] = lv[u];
+        const int wf = Ds + c.NLc, T = c.T, NL = c.NL;
+        const int ns = nvalid * Ds;                                       // <= 1024 (Ds <= 32)
+        {   // the tile's final state rows are still in LDS: the new-state columns of the last body, or (k == 0) the staged initial rows;
+            // its label rows were staged at kernel start
+            RowCol rc(lane, Ds);
+            for (int t = lane; t < ns; t += 64, rc.next()) scr[t] = k > 0 ? X[rc.i * KP + c_aggs + rc.c] : X[t];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const bool on = lane < nvalid && c.mask[i0 + (lane < nvalid ? lane : 0)];
-        if (on) {
+        if (out_on) {
             float y[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) y[j] = 0.0f;
@@ -292,7 +395,7 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
                 for (int q = 0; q < 8; ++q)
                     if (q < T) v[q] = gnn_act(y[q], c.oact);
             }
-            float *o = c.out + (int64_t)c.mask_pos[i0 + lane] * T;
+            float *o = c.out + (int64_t)out_pos * T;
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (q < T) {
@@ -319,23 +422,22 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
 }
 
 template <int LAYERS, int ACT>
-static bool small_launch_k(int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes, hipStream_t st)
+static bool small_launch_k(int kk0, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
 #define GNN_SMALL_K(K)                                                                                                      \
     if (kk0 == K) {                                                                                                         \
-        if (rnd == 8) hipLaunchKernelGGL((k_small_loop<LAYERS, ACT, K, 8>), grid, 64, lds_bytes, st, a, c);                   \
-        else hipLaunchKernelGGL((k_small_loop<LAYERS, ACT, K, 4>), grid, 64, lds_bytes, st, a, c);                            \
+        hipLaunchKernelGGL((k_small_loop<LAYERS, ACT, K>), grid, 64, lds_bytes, st, a, c);                                    \
         return true;                                                                                                        \
     }
-    GNN_SMALL_K(12) GNN_SMALL_K(24) GNN_SMALL_K(36) GNN_SMALL_K(48)
+    GNN_SMALL_K(8) GNN_SMALL_K(12) GNN_SMALL_K(16) GNN_SMALL_K(24) GNN_SMALL_K(32) GNN_SMALL_K(36) GNN_SMALL_K(40) GNN_SMALL_K(48)
 #undef GNN_SMALL_K
     return false;
 }
 
 template <int LAYERS>
-static bool small_launch_act(int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes, hipStream_t st)
+static bool small_launch_act(int act, int kk0, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes, hipStream_t st)
 {
-#define GNN_SMALL_CASE(A) case A: return small_launch_k<LAYERS, A>(kk0, rnd, a, c, grid, lds_bytes, st);
+#define GNN_SMALL_CASE(A) case A: return small_launch_k<LAYERS, A>(kk0, a, c, grid, lds_bytes, st);
     switch (act) {
         GNN_SMALL_CASE(GNN_ACT_LINEAR) GNN_SMALL_CASE(GNN_ACT_RELU) GNN_SMALL_CASE(GNN_ACT_SELU) GNN_SMALL_CASE(GNN_ACT_ELU)
         GNN_SMALL_CASE(GNN_ACT_TANH) GNN_SMALL_CASE(GNN_ACT_SIGMOID)
@@ -346,12 +448,12 @@ static bool small_launch_act(int act, int kk0, int rnd, const GnnFusedArgs &a, c
 
 }   // namespace gnn_fused_dev
 
-bool gnn_small_launch(int layers, int act, int kk0, int rnd, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
+bool gnn_small_launch(int layers, int act, int kk0, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
                       hipStream_t st)
 {
     using namespace gnn_fused_dev;
-    if (layers == 1) return small_launch_act<1>(act, kk0, rnd, a, c, grid, lds_bytes, st);
-    if (layers == 2) return small_launch_act<2>(act, kk0, rnd, a, c, grid, lds_bytes, st);
-    if (layers == 3) return small_launch_act<3>(act, kk0, rnd, a, c, grid, lds_bytes, st);
+    if (layers == 1) return small_launch_act<1>(act, kk0, a, c, grid, lds_bytes, st);
+    if (layers == 2) return small_launch_act<2>(act, kk0, a, c, grid, lds_bytes, st);
+    if (layers == 3) return small_launch_act<3>(act, kk0, a, c, grid, lds_bytes, st);
     return false;
 }
