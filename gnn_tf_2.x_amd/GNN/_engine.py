@@ -475,9 +475,10 @@ class Loop:
         return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
                     bn_batch_state=bns[:kk], bn_batch_output=bno)
 
-    def set_slice_exchange(self, on: bool = True):
-        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows."""
-        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(1 if on else 0)))
+    def set_slice_exchange(self, on=True):
+        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows.  on = True / 1: the return
+        all-to-all runs block by block beside the aggregation (second stream); on = 2: whole slice, then one all-to-all."""
+        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(int(on))))
 
     def update_moving_statistics(self, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
         """gnn_loop_update_moving_statistics: the moving statistics of both nets from the last train_forward, on the device."""

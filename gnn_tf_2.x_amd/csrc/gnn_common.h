@@ -195,6 +195,7 @@ struct gnn_comm {
     void *nccl = nullptr;       // ncclComm_t (RCCL communicators)
     gnn_comm_group *grp = nullptr;   // loopback communicators
     hipStream_t stream = nullptr;
+    hipStream_t xstream = nullptr;   // second stream: transfers that run beside the kernels of `stream` (sliced exchange, return all-to-all); created on first use
     double *scratch = nullptr;  // device, for allreduce_max
     // loops created on this communicator use its stream (and, loopback, its group): the communicator outlives them.  gnn_comm_destroy
     // with loops still alive only marks it closed; the last gnn_loop_destroy then releases it (either destruction order is safe).
@@ -259,6 +260,9 @@ struct gnn_loop {
     float *sl_state = nullptr;              // [N_pad, Cs]: this rank's column slice of every node's state
     float *sl_agg = nullptr;                // [N_pad, Cs]: its aggregate
     float *sl_recv = nullptr;               // [world][shard_rows, Cs]: the aggregate of the owned rows, one block per source rank
+    bool sl_pipeline = true;                // the return all-to-all runs block by block on the communicator's second stream, under the aggregation of the next block
+    std::vector<hipEvent_t> sl_ev;          // [world]: block t of the aggregation is complete (recorded on `stream`)
+    hipEvent_t sl_done = nullptr;           // this rank's transfers of the body are complete (recorded on the second stream)
     float *agg_own = nullptr;               // [shard_rows, Ds]: aggregated states of the owned rows (GNN.py:234), input of the body
     void *train_ctx = nullptr;              // gnn_train.hip: what train_forward leaves for train_backward
     void *train_arena = nullptr;            // gnn_train.hip: device scratch slabs kept from step to step

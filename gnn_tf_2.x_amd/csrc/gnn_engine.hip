@@ -1174,11 +1174,13 @@ extern "C" int gnn_comm_destroy(gnn_comm *c)
     (void)hipSetDevice(c->device);
     if (c->grp) {
         if (--c->grp->refs == 0) { (void)hipStreamDestroy(c->grp->stream); delete c->grp; }
+        if (c->xstream) (void)hipStreamDestroy(c->xstream);
         delete c;
         return GNN_OK;
     }
     if (c->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(c->nccl);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     (void)hipFree(c->scratch);
     delete c;
     return GNN_OK;
@@ -1533,18 +1535,69 @@ static int slice_step_pack(gnn_loop *l, int k)
     return slice_alltoall(l, 0);
 }
 
+// Aggregation of the rank's column slice + the return all-to-all.  Pipelined form (default): the rows are aggregated in P blocks, one per
+// destination rank, in the order rank + 1, rank + 2, ..., rank (every step of the schedule is a permutation: at step t rank r sends
+// to r + 1 + t and receives from r - 1 - t, so no link carries two blocks at once), and block t travels on the communicator's second
+// stream while block t + 1 is aggregated on the loop's stream; only the last block (the rank's own: a device copy) is exposed.
 static int slice_step_aggregate(gnn_loop *l, int k)
 {
     const gnn_graph *g = l->g;
-    const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
-    int rc = gnn_launch_spmm(l->stream, g->sh->full_rows, g->sh->full_indptr, g->sh->full_src, g->sh->full_w, l->sl_state, l->Cs, l->Cs, l->sl_agg, l->Cs, gate, l->world);
-    if (rc) return rc;
-    return slice_alltoall(l, 1);
+    const int P = l->world;
+    const int *gate = l->flags + (size_t)k * P * GNN_FLAG_WORDS;
+    if (!l->sl_pipeline) {
+        int rc = gnn_launch_spmm(l->stream, g->sh->full_rows, g->sh->full_indptr, g->sh->full_src, g->sh->full_w, l->sl_state, l->Cs, l->Cs, l->sl_agg, l->Cs, gate, P);
+        if (rc) return rc;
+        return slice_alltoall(l, 1);
+    }
+    gnn_comm *cm = l->comm;
+    if (!cm->xstream) HIPCHK(hipStreamCreateWithFlags(&cm->xstream, hipStreamNonBlocking));
+    if ((int)l->sl_ev.size() < P) {
+        const size_t old = l->sl_ev.size();
+        l->sl_ev.resize((size_t)P, nullptr);
+        for (size_t i = old; i < l->sl_ev.size(); ++i) HIPCHK(hipEventCreateWithFlags(&l->sl_ev[i], hipEventDisableTiming));
+    }
+    if (!l->sl_done) HIPCHK(hipEventCreateWithFlags(&l->sl_done, hipEventDisableTiming));
+    const size_t block = (size_t)l->shard_rows * l->Cs;
+    for (int t = 0; t < P; ++t) {
+        const int q = (l->rank + 1 + t) % P, from = ((l->rank - 1 - t) % P + P) % P;
+        const int64_t r0 = (int64_t)q * l->shard_rows, r1 = std::min<int64_t>(r0 + l->shard_rows, g->sh->full_rows);
+        if (r1 > r0) {
+            int rc = gnn_launch_spmm(l->stream, r1 - r0, g->sh->full_indptr + r0, g->sh->full_src, g->sh->full_w, l->sl_state, l->Cs, l->Cs,
+                                     l->sl_agg + (size_t)r0 * l->Cs, l->Cs, gate, P);
+            if (rc) return rc;
+        }
+        HIPCHK(hipEventRecord(l->sl_ev[t], l->stream));
+        HIPCHK(hipStreamWaitEvent(cm->xstream, l->sl_ev[t], 0));
+        const float *src = l->sl_agg + (size_t)q * block;
+        if (cm->grp) {
+            gnn_loop *peer = cm->grp->member[q];
+            if (!peer) return gnn_fail(GNN_ERR_STATE, "loopback rank %d has no loop: create one loop per rank and run them with gnn_loop_run_group", q);
+            if (!peer->slice_mode) return gnn_fail(GNN_ERR_STATE, "rank %d does not use the feature-sliced exchange", q);
+            HIPCHK(hipMemcpyAsync(peer->sl_recv + (size_t)l->rank * block, src, sizeof(float) * block, hipMemcpyDeviceToDevice, cm->xstream));
+        } else if (q == l->rank) {
+            HIPCHK(hipMemcpyAsync(l->sl_recv + (size_t)l->rank * block, src, sizeof(float) * block, hipMemcpyDeviceToDevice, cm->xstream));
+        } else {
+            NCCLCHK(g_rccl.GroupStart());
+            NCCLCHK(g_rccl.Send(src, block, NCCL_FLOAT32, q, cm->nccl, cm->xstream));
+            NCCLCHK(g_rccl.Recv(l->sl_recv + (size_t)from * block, block, NCCL_FLOAT32, from, cm->nccl, cm->xstream));
+            NCCLCHK(g_rccl.GroupEnd());
+        }
+    }
+    HIPCHK(hipEventRecord(l->sl_done, cm->xstream));
+    return GNN_OK;
 }
 
 static int slice_step_unpack(gnn_loop *l, int k)
 {
     const int *gate = l->flags + (size_t)k * l->world * GNN_FLAG_WORDS;
+    if (l->sl_pipeline) {          // the blocks of this rank's rows have arrived: its own transfers (RCCL: each carries the matching receive), or every member's (loopback: they push)
+        if (l->comm->grp) {
+            for (int p = 0; p < l->world; ++p) {
+                gnn_loop *peer = l->comm->grp->member[p];
+                if (peer && peer->sl_done) HIPCHK(hipStreamWaitEvent(l->stream, peer->sl_done, 0));
+            }
+        } else if (l->sl_done) HIPCHK(hipStreamWaitEvent(l->stream, l->sl_done, 0));
+    }
     if (l->g->n_rows) {
         if (l->Cs % 4 == 0)
             hipLaunchKernelGGL((k_slice_unpack<4>), cdiv(l->g->n_rows * (l->Ds / 4), 256), 256, 0, l->stream, l->g->n_rows, l->shard_rows, l->Ds, l->Cs,
@@ -1578,6 +1631,7 @@ extern "C" int gnn_loop_set_slice_exchange(gnn_loop *l, int on)
         if ((rc = zero_on_stream(l->sl_agg, sizeof(float) * std::max<size_t>(slice, 1), l->stream))) return rc;      // rows past N_global are never written
     }
     l->slice_mode = true;
+    l->sl_pipeline = on != 2;          // 2: the whole slice is aggregated, then one grouped all-to-all (round-2 form; kept for comparison)
     return GNN_OK;
 }
 
@@ -2147,6 +2201,8 @@ extern "C" int gnn_loop_destroy(gnn_loop *l)
     if (l->ng_host) (void)hipHostFree(l->ng_host);
     (void)hipFree(l->edge_dst); (void)hipFree(l->edge_rows); (void)hipFree(l->edge_labels); (void)hipFree(l->edge_inc_ptr); (void)hipFree(l->edge_inc);
     (void)hipFree(l->sl_send); (void)hipFree(l->sl_state); (void)hipFree(l->sl_agg); (void)hipFree(l->sl_recv); (void)hipFree(l->agg_own);
+    for (hipEvent_t ev : l->sl_ev) if (ev) (void)hipEventDestroy(ev);
+    if (l->sl_done) (void)hipEventDestroy(l->sl_done);
     (void)hipFree(l->ng_ip); (void)hipFree(l->ng_node); (void)hipFree(l->ng_w); (void)hipFree(l->ng_out); (void)hipFree(l->ng_part);
     if (!l->comm && l->stream) (void)hipStreamDestroy(l->stream);
     gnn_comm *comm = l->comm;

@@ -63,6 +63,11 @@ struct GnnSmallCtl {
     float *xs;               // padded exchange rows [2][tiles * 32][DP] (gnn_small.hip, small_gather_padded): the state between bodies
     int DP;                  // 16 (Ds <= 16) or 32 floats per exchange row
     int rnd;                 // arcs per gather round for DP == 16 (4, or 8 when some row has more than 8 arcs)
+    // 16-node-tile form (gnn_small16.hip): the Keras-layout kernels W[din][dout] (its A operands are read from them directly) and the
+    // row stride of its LDS tile
+    const float *Wraw[GNN_FUSED_MAXL];
+    int din[GNN_FUSED_MAXL], dout[GNN_FUSED_MAXL];
+    int KP16;
     int *zero_words;         // the OTHER run's gate words (double-buffered by run parity): zeroed here for the next run
     int n_words;
     int max_iter;
@@ -83,6 +88,9 @@ struct GnnSmallCtl {
 };
 bool gnn_small_launch(int layers, int act, int kk0, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes,
                       hipStream_t st);
+
+bool gnn_small16_launch(int layers, int act, int s0, const GnnFusedArgs &a, const GnnSmallCtl &c, unsigned grid, size_t lds_bytes, hipStream_t st);
+size_t gnn_small16_lds_bytes(int kp16);
 
 // one per translation unit gnn_fused_l{1,2,3}.hip; false = no instantiation for (act, nt, ntl)
 bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

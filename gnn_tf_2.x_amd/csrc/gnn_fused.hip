@@ -472,10 +472,18 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     c.init = l->D ? l->state_init : g->nodes + (size_t)g->own_off * g->NL;      // D == 0: NL == Ds (GNN.py:265)
     c.kfinal = l->kfinal_dev;
     c.host_result = l->kfinal_host;                                   // pinned, device-visible: no copy back
-    const unsigned grid = (unsigned)((g->n_rows + 31) / 32);
+    // 16-node tiles (gnn_small16.hip) while twice the workgroups are still resident at once: a body is a chain of latencies, and a
+    // 16-node tile's dense layers and activations are half as long
+    bool tile16 = g->n_rows <= 16 * 256 && a.in_s <= 96;
+#ifdef GNN_DIAG
+    static const int tile_env = getenv("GNN_SMALL_TILE") ? atoi(getenv("GNN_SMALL_TILE")) : 0;
+    if (tile_env == 32) tile16 = false;
+#endif
+    const int rows_per_tile = tile16 ? 16 : 32;
+    const unsigned grid = (unsigned)((g->n_rows + rows_per_tile - 1) / rows_per_tile);
     c.DP = l->Ds <= 16 ? 16 : 32;
     {   // padded exchange rows: allocated with the first persistent run of the loop, never initialised (every row is written before it is read)
-        const size_t need = (size_t)2 * grid * 32 * c.DP;
+        const size_t need = (size_t)2 * grid * rows_per_tile * c.DP;
         if (l->small_xs_floats < need) {
             if (l->small_xs) (void)hipFree(l->small_xs);
             l->small_xs = nullptr; l->small_xs_floats = 0;
@@ -544,7 +552,17 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
         a.stamps = small_stamp_buf;
     }
 #endif
-    if (!gnn_small_launch(p.layers, p.act, kk_small, a, c, grid, lds, l->stream))
+    bool launched;
+    if (tile16) {
+        const gnn_mlp *m = l->st;
+        for (int q = 0; q < p.layers; ++q) { c.Wraw[q] = m->W[q]; c.din[q] = m->dims[q]; c.dout[q] = m->dims[q + 1]; }
+        int s0 = (a.in_s + 3) / 4;
+        s0 = (s0 + 3) / 4 * 4;                                       // instantiated: 4, 8, ..., 24 K-steps of 4
+        c.KP16 = std::max((a.in_s + 3) / 4 * 4, 4 * s0);
+        if (c.KP16 % 8 == 0) c.KP16 += 4;                            // rows 16 bytes apart in the banks: the B-operand column reads do not conflict
+        launched = gnn_small16_launch(p.layers, p.act, s0, a, c, grid, gnn_small16_lds_bytes(c.KP16), l->stream);
+    } else launched = gnn_small_launch(p.layers, p.act, kk_small, a, c, grid, lds, l->stream);
+    if (!launched)
         return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
     HIPCHK(hipGetLastError());
 #ifdef GNN_DIAG

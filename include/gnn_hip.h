@@ -282,7 +282,11 @@ int gnn_graph_create_halo(int64_t n_nodes_global, int rank, int world, int64_t h
  * iteration move column slices of the owned rows in and aggregated slices back: 2 (P - 1) / P^2 of N Ds floats received per rank
  * and iteration instead of (P - 1) / P (56 MB instead of 224 MB at N = 1 M, Ds = 64, P = 8).  Bit-identical results.
  *   gnn_graph_set_full_adjacency  the whole graph's CSR by destination (global ids) beside the shard's own rows
- *   gnn_loop_set_slice_exchange   on != 0: use it (Ds must be a multiple of the world size); every rank of the job alike */
+ *   gnn_loop_set_slice_exchange   on != 0: use it (Ds must be a multiple of the world size); every rank of the job alike.
+ *                                 on == 1: the slice is aggregated in P row blocks (one per destination rank, in the order rank + 1, ...,
+ *                                 rank) and block t is sent on a second stream while block t + 1 is aggregated - the return all-to-all is
+ *                                 hidden behind the aggregation except for the rank's own block; on == 2: the whole slice, then one grouped
+ *                                 all-to-all (kept for comparison) */
 int gnn_graph_set_full_adjacency(gnn_graph *g, int64_t n_global, const int32_t *indptr, const int32_t *adj_src, const float *adj_w);
 int gnn_loop_set_slice_exchange(gnn_loop *l, int on);
 /* In-process LOOPBACK group: `world` communicators on ONE device sharing one stream; the exchange steps become

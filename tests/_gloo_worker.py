@@ -93,6 +93,29 @@ def main():
             buf[:rows.shape[0]] = rows
             return buf
 
+        def return_pipelined(slice_all):
+            # the schedule of slice_step_aggregate (csrc/gnn_engine.hip, gnn_loop_set_slice_exchange(l, 1)): the slice is aggregated in one
+            # row block per destination rank in the order rank + 1, ..., rank; at step t rank r sends block (r + 1 + t) % P to that rank
+            # and receives its own rows' block from rank (r - 1 - t) % P - a permutation per step; the last step is the rank's own block
+            back = [None] * world
+            for t in range(world):
+                q, frm = (rank + 1 + t) % world, (rank - 1 - t) % world
+                r0, cnt = ranges[q]
+                rows_ip = full[0][r0:r0 + cnt + 1]
+                block = np.zeros((cnt, cs), np.float32)
+                if cnt:      # rows r0 .. r0 + cnt of the whole graph's CSR (absolute arc offsets, like indptr + r0 on the device)
+                    sub = (rows_ip - rows_ip[0], full[1][rows_ip[0]:rows_ip[-1]], full[2][rows_ip[0]:rows_ip[-1]])
+                    block = corc.spmm(sub, np.ascontiguousarray(slice_all))
+                if q == rank:
+                    assert frm == rank
+                    back[rank] = pad(block)
+                else:
+                    recv = torch.zeros(shard, cs)
+                    reqs = [dist.isend(torch.from_numpy(pad(block)), q), dist.irecv(recv, frm)]
+                    for r_ in reqs: r_.wait()
+                    back[frm] = recv.numpy()
+            return back
+
         own = state0[rb:rb + nr].copy()
         go = any_flag(orc.not_converged(own, np.ones((nr, d), np.float32), thr).any())
         k_sl = 0
@@ -101,6 +124,8 @@ def main():
             slice_all = to_global(np.concatenate(sent))                                     # [n, cs]
             agg_slice = corc.spmm(full, np.ascontiguousarray(slice_all))                     # [n, cs]: all nodes, my columns
             back = alltoall([pad(agg_slice[ranges[q][0]:ranges[q][0] + ranges[q][1]]) for q in range(world)])       # rank q's rows, my columns
+            back_p = return_pipelined(slice_all)                                             # the same through the block-by-block schedule
+            assert all(np.array_equal(x, y) for x, y in zip(back, back_p)), 'pipelined return all-to-all differs from the grouped one'
             agg_own = np.concatenate([b[:nr] for b in back], axis=1)                         # [nr, d]: my rows, all columns
             inp = np.concatenate([own, s['nodes'][rb:rb + nr], agg_own, agg_nodes, agg_arcs], axis=1)
             new = corc.mlp_forward(inp, st['weights'], st['activations'], True)

@@ -296,13 +296,16 @@ def test_loopback_group_errors():
     assert e.Loop.run_group(loops) == corc.loop_node(g, st, ou, 4, 5, 0.01, s0)[0]
 
 
+@pytest.mark.parametrize('form', [1, 2])
 @pytest.mark.parametrize('world', [2, 4, 8])
 @pytest.mark.parametrize('n,d,hidden', [(1000, 8, (16,)), (4099, 64, (128, 128)), (333, 16, (7,))])
-def test_feature_sliced_exchange_bit_exact(n, d, hidden, world):
+def test_feature_sliced_exchange_bit_exact(n, d, hidden, world, form):
     """gnn_loop_set_slice_exchange: every rank aggregates ITS columns of the state for all nodes over the whole graph's adjacency
     (two all-to-all steps per iteration instead of the all-gather of rows).  The fmaf chain of an aggregated element is the
     same CSR-ordered chain as in the replicated layouts: impl 0 / 1 bit-identical to the C oracle, impl 2 within the tolerance
-    of the unsharded run; n = 333 on 8 ranks: the last ranks own nothing, n = 4099: short last shard, partial tiles."""
+    of the unsharded run; n = 333 on 8 ranks: the last ranks own nothing, n = 4099: short last shard, partial tiles.
+    form 1 (default): the slice is aggregated in one row block per destination rank and each block is sent on a second stream while
+    the next one is aggregated; form 2: whole slice, then one grouped all-to-all.  Same bits."""
     e = _engine()
     g, st, ou, s0 = _case(300 + n + world, n, d, hidden=hidden)
     indptr, adj_src, adj_w, _, _ = _csr_parts(g)
@@ -312,7 +315,7 @@ def test_feature_sliced_exchange_bit_exact(n, d, hidden, world):
         comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 30, 0.01, s0, world, impl)
         for gr, lp in zip(graphs, loops):
             gr.set_full_adjacency(n, indptr, adj_src, adj_w)
-            lp.set_slice_exchange(True)
+            lp.set_slice_exchange(form)
         return comms, graphs, loops, ranges
 
     for impl in (1, 0):
