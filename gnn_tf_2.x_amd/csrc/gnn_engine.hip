@@ -1889,6 +1889,7 @@ extern "C" int gnn_loop_run_group(gnn_loop **loops, int n, float *k_out)
         ARGCHK(loops[r]->max_iter == loops[0]->max_iter && loops[r]->thr == loops[0]->thr && loops[r]->Ds == loops[0]->Ds, "ranks were configured differently");
         // the exchange protocol of the whole group follows rank 0: a rank on another layout / arithmetic would skip or misread an exchange
         ARGCHK(loops[r]->slice_mode == loops[0]->slice_mode && loops[r]->Cs == loops[0]->Cs && loops[r]->impl_req == loops[0]->impl_req &&
+               (!loops[0]->slice_mode || loops[r]->sl_pipeline == loops[0]->sl_pipeline) &&
                (loops[r]->g->halo_world != 0) == (loops[0]->g->halo_world != 0),
                "rank %d uses another exchange layout or arithmetic (slice %d/%d, impl %d/%d) than rank 0", r, (int)loops[r]->slice_mode, (int)loops[0]->slice_mode,
                loops[r]->impl_req, loops[0]->impl_req);

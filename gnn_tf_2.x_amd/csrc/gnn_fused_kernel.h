@@ -1228,6 +1228,11 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // Tiles are handed out by a device-wide ticket counter; a wave knows its next tile one tile ahead (ticket drawn at the end
     // of the previous tile's dense layers), early enough to have that tile's row pointers and first gather ids requested.
     // (Serving the tickets heaviest-tile-first was measured: 1 % slower on the BASELINE graph.)
+#ifdef GNN_DIAG     // diagnostic build: variant bit 3 makes ONE wave of the launch start late (wave 0 of workgroup 0, about 250 us) - with bit 4
+    // (the wasted look-ahead draw of single-ticket launches as it was before the fix, below) that wave then finds its tile's number gone
+    if ((a.variant & 8) && blockIdx.x == 0 && wave == 0)
+        for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     int tile = 0, next_tile = 0;
     if (lane == 0) { tile = atomicAdd(a.tile_ctr, 1); next_tile = a.single_ticket ? 0x3fffffff : atomicAdd(a.tile_ctr, 1); }
     tile = __builtin_amdgcn_readfirstlane(tile) + a.tile_base;
@@ -1334,8 +1339,15 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // Requests for the tile after next (ticket) and for the next tile (ids / weights of its first gather batch): issued HERE,
     // behind the last weight loads, because vector-memory results return in issue order - in front of the dense layers these
     // HBM-latency loads would hold up every weight wait - and the epilogue / norm / stores below cover their latency.
-    int next2_tile = 0;
-    if (lane == 0) next2_tile = atomicAdd(a0.tile_ctr, 1);
+    // (single_ticket: NO draw here.  A wave of such a launch never runs a second tile, so the ticket would be thrown away - and if a
+    // wave that starts late had not drawn its first ticket yet, the discarded number could be a real tile that nobody then runs.)
+    int next2_tile = 0x3fffffff;
+#ifdef GNN_DIAG
+    if (lane == 0 && (!a0.single_ticket || (a0.variant & 16))) next2_tile = atomicAdd(a0.tile_ctr, 1);
+    if (a0.single_ticket) next2_tile = 0x3fffffff;
+#else
+    if (lane == 0 && !a0.single_ticket) next2_tile = atomicAdd(a0.tile_ctr, 1);
+#endif
     const int ip_next = tile_rowptr_clamp(a, next_tile, lane, ip_next_raw);
     int src_next = 0;
     float w_next = 0.0f;
