@@ -1084,7 +1084,14 @@ enum { NCCL_INT32 = 2, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8, NCCL_MAX = 2 };
 static int rccl_load()
 {
     if (g_rccl.h) return GNN_OK;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    void *h = nullptr;
+    // GNN_RCCL_LIBRARY=<path>: the collectives library to load instead of the system's RCCL (another RCCL build; the multi-process tests
+    // point it at their stand-in transport, tests/mock_rccl, to run several ranks on one GPU).  No fallback when it is set.
+    if (const char *path = getenv("GNN_RCCL_LIBRARY")) {
+        h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return gnn_fail(GNN_ERR_COMM, "cannot load GNN_RCCL_LIBRARY=%s: %s", path, dlerror());
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) return gnn_fail(GNN_ERR_COMM, "cannot load librccl: %s", dlerror());

@@ -1,0 +1,56 @@
+"""One rank of tests/test_gpu_multiprocess.py: the engine's multi-process path (gnn_comm_create, the RCCL call sites of loop_exchange /
+slice_alltoall / slice_step_aggregate, the sharded readout) with several PROCESSES on one GPU, over the stand-in transport of
+tests/mock_rccl (GNN_RCCL_LIBRARY).  Runs every exchange layout on the same small graph and writes k, the rank's state and output rows
+per layout to <out>/rank<r>.npz; the test compares them with the C oracle."""
+import os, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'gnn_tf_2.x_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+
+
+def main():
+    rank, world, out_dir = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), sys.argv[1]
+    import bench
+    from GNN import _engine as e
+    import test_gpu_sharded as S
+    n, d = int(os.environ.get('MP_NODES', 4099)), 8
+    g, st, ou, s0 = S._case(4242, n, d, hidden=(16,))
+    indptr, adj_src, adj_w, arc_w, arc_lab = S._csr_parts(g)
+    mask = np.logical_and(g['set_mask'], g['output_mask'])
+    res = {}
+    for li, layout in enumerate(('full', 'halo', 'slice1', 'slice2')):
+        if layout.startswith('slice') and d % world: continue
+        os.environ['GNN_BENCH_RDV'] = os.path.join(out_dir, f'id_{layout}')
+        uid, _ = bench.rendezvous_id(rank, world, e)
+        comm = e.Comm(uid, rank, world, 0)                       # every rank on device 0
+        mst, mou = e.Mlp(st['weights'], st['activations'], st['batch_normalization']), e.Mlp(ou['weights'], ou['activations'], ou['batch_normalization'])
+        rb, nr, ip, src, w, aw, al_ = e.shard_csr(n, rank, world, indptr, adj_src, adj_w, arc_w, arc_lab)
+        if layout == 'halo':
+            h = e.shard_halo(n, rank, world, indptr, adj_src, g['nodes'])
+            gr = e.Graph.halo(n, rank, world, h['block'], h['send_rows'], ip, h['adj_src'], w, aw, al_, h['nodes'], mask[rb:rb + nr])
+        else:
+            gr = e.Graph(n, ip, src, w, aw, al_, g['nodes'], mask[rb:rb + nr], row_begin=rb)
+        for impl in (1, 2):
+            lp = e.Loop(gr, mst, mou, d, 30, 0.01, comm)
+            lp.set_impl(impl)
+            lp.set_state0(s0[rb:rb + nr])
+            if layout.startswith('slice'):
+                gr.set_full_adjacency(n, indptr, adj_src, adj_w)
+                lp.set_slice_exchange(int(layout[-1]))
+            k = lp.run()
+            k2 = lp.run()                                         # a second Loop on the same communicator
+            assert k2 == k
+            res[f'{layout}_{impl}_k'] = np.float64(k)
+            res[f'{layout}_{impl}_state'] = lp.state()
+            res[f'{layout}_{impl}_out'] = lp.output()
+            res[f'{layout}_{impl}_max'] = np.float64(comm.allreduce_max(float(rank + 1)))
+            lp.close()
+        comm.close()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **res)
+    print(f'MP_WORKER_OK rank={rank}')
+
+
+if __name__ == '__main__':
+    main()

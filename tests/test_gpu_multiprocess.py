@@ -1,0 +1,85 @@
+"""The engine's multi-PROCESS path on one GPU.
+
+RCCL refuses two ranks on one device, and the builder's boxes have one GPU: the sharded kernels run in an in-process loopback group
+(test_gpu_sharded.py), but the code a real job goes through - one process per rank, the unique-id rendezvous, gnn_comm_create, the RCCL
+call sites (grouped all-gathers of state rows / boundary blocks and flags, the all-to-alls of the feature-sliced exchange, the
+point-to-point schedule of its pipelined return, the max all-reduce) - had never executed with more than one rank.  Here it does, over a
+stand-in transport (tests/mock_rccl: the same entry points, data through /dev/shm, blocking), selected with GNN_RCCL_LIBRARY.  What this
+checks: ORDER, peers, counts and offsets of every call on every rank (a mismatch deadlocks into the transport's time-out or gives wrong
+rows) and the results against the C oracle.  What it cannot check: RCCL itself, xGMI, overlap, timing.  Also: `bench.py --gpus N`
+end to end through its own launcher with all ranks on device 0 (GNN_BENCH_ONE_DEVICE=1)."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as corc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, 'tests', 'mock_rccl', 'libmock_rccl.so')
+
+
+def _mock():
+    if not os.path.exists(MOCK):
+        subprocess.run(['make', '-C', os.path.dirname(MOCK)], check=True, capture_output=True)
+    return MOCK
+
+
+def _env(rank, world, extra=None):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), GNN_RCCL_LIBRARY=_mock(), OMP_NUM_THREADS='2')
+    env.update(extra or {})
+    return env
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_as_processes_match_oracle(world):
+    """world processes, every exchange layout, impl 1 bit-identical to the C oracle (k, states, outputs), impl 2 within tolerance."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import test_gpu_sharded as S
+    n, d = 4099, 8
+    g, st, ou, s0 = S._case(4242, n, d, hidden=(16,))
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 30, 0.01, s0)
+    with tempfile.TemporaryDirectory() as out:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_mp_worker.py'), out], env=_env(r, world), cwd=ROOT,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = []
+        for p in procs:
+            try:
+                logs.append(p.communicate(timeout=420)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs: q.kill()
+                raise
+        assert all(p.returncode == 0 for p in procs), '\n'.join(l[-1500:] for l in logs)
+        res = [np.load(os.path.join(out, f'rank{r}.npz')) for r in range(world)]
+    layouts = ['full', 'halo'] + (['slice1', 'slice2'] if d % world == 0 else [])
+    for layout in layouts:
+        for impl in (1, 2):
+            ks = {float(r[f'{layout}_{impl}_k']) for r in res}
+            assert ks == {float(kc)}, (layout, impl, ks, kc)
+            state = np.concatenate([r[f'{layout}_{impl}_state'] for r in res])
+            outp = np.concatenate([r[f'{layout}_{impl}_out'] for r in res])
+            assert state.shape == sc.shape and outp.shape == oc.shape
+            if impl == 1:
+                assert np.array_equal(state, sc) and np.array_equal(outp, oc), (layout, int(np.sum(state != sc)))
+            else:
+                assert np.max(np.abs(state - sc)) < 2e-6 * max(1.0, float(np.max(np.abs(sc)))) and np.max(np.abs(outp - oc)) < 2e-6, layout
+            assert {float(r[f'{layout}_{impl}_max']) for r in res} == {float(world)}      # gnn_comm_allreduce_max over the ranks
+
+
+@pytest.mark.parametrize('gpus,exchange', [(2, 'auto'), (4, 'auto'), (3, 'halo')])
+def test_bench_launcher_runs_all_ranks_end_to_end(gpus, exchange):
+    """`python bench.py --gpus N` bare: the launcher starts N rank processes, they rendezvous, shard the graph, run the timed Loops through
+    the communicator and rank 0 prints the JSON line (a reduced graph; all ranks on device 0 over the stand-in transport)."""
+    env = dict(os.environ, GNN_RCCL_LIBRARY=_mock(), GNN_BENCH_ONE_DEVICE='1', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'): env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--steps', '2', '--warmup', '1', '--nodes', '60000',
+           '--exchange', exchange, '--no-cpu-baseline', '--no-other-configs']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == gpus and line['steps'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
