@@ -291,3 +291,17 @@ def test_optimizer_counts_a_device_step_only_after_it_succeeded_and_restarts_on_
     assert opt.iterations == 1 and opt._slot_token is not token and np.allclose(new[0], p - 0.01, atol=1e-6)
     opt.device_step_args()                                      # and back: again from zero
     assert opt.iterations == 0 and opt._m is None
+
+
+def test_stand_in_transport_exports_what_the_engine_binds():
+    """tests/mock_rccl (the stand-in transport of tests/test_gpu_multiprocess.py) builds and exports every entry point rccl_load binds
+    (csrc/gnn_engine.hip): a missing symbol would only show on the GPU box otherwise."""
+    import ctypes, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(['make', '-C', os.path.join(root, 'tests', 'mock_rccl')], check=True, capture_output=True)
+    src = open(os.path.join(root, 'gnn_tf_2.x_amd', 'csrc', 'gnn_engine.hip')).read()
+    bound = set(re.findall(r'"(nccl[A-Za-z]+)"', src))
+    assert {'ncclGetUniqueId', 'ncclCommInitRank', 'ncclAllGather', 'ncclSend', 'ncclRecv', 'ncclGroupStart', 'ncclGroupEnd'} <= bound
+    lib = ctypes.CDLL(os.path.join(root, 'tests', 'mock_rccl', 'libmock_rccl.so'))
+    for name in bound:
+        assert hasattr(lib, name), name
