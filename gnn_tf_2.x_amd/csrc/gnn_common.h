@@ -276,6 +276,9 @@ int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const
 int gnn_launch_dense(hipStream_t st, int64_t n, int n_in, int n_out, const float *X, int64_t ldx, const float *W, const float *b,
                      int act, float *Y, int64_t ldy);
 int gnn_launch_check(hipStream_t st, int64_t n_rows, int d, const float *s, const float *so, float thr, int *flag_rank_base);
+// all-gather of `count` 4-byte elements per rank on an RCCL communicator (one process per rank; recv: [world][count], in place when
+// send == recv + rank * count), queued on st - for the translation units that do not see the RCCL table (gnn_train.hip)
+int gnn_comm_allgather32(gnn_comm *c, const void *send, void *recv, size_t count, hipStream_t st);
 // GNNedgeBased.apply_filters on `state` (training path): feats [n_edge_masked, 2 (Ds + NLc) + AL]
 int gnn_launch_feats_edge(hipStream_t st, const gnn_loop *l, const float *state, float *feats);
 

@@ -1174,6 +1174,13 @@ extern "C" int gnn_comm_allreduce_max(gnn_comm *c, double *value)
     return GNN_OK;
 }
 
+int gnn_comm_allgather32(gnn_comm *c, const void *send, void *recv, size_t count, hipStream_t st)
+{
+    if (!c || c->grp || !c->nccl) return gnn_fail(GNN_ERR_UNSUPPORTED, "this exchange needs an RCCL communicator (one process per rank), not a loopback group");
+    NCCLCHK(g_rccl.AllGather(send, recv, count, NCCL_INT32, c->nccl, st));
+    return GNN_OK;
+}
+
 extern "C" int gnn_comm_destroy(gnn_comm *c)
 {
     if (!c) return GNN_OK;

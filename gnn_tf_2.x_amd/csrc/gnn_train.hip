@@ -308,6 +308,46 @@ __global__ void __launch_bounds__(256) k_bn_apply(int64_t n, int F, int cw_shift
     }
 }
 
+// ---- BatchNormalization statistics over the rows of ALL ranks (sharded training forward) ----------------------------------------------
+// k_bn_local: the rank's chunk statistics merged in chunk order into ONE triple per feature, tri = [count | mean | M2] (3 F floats);
+// the triples of all ranks are all-gathered (3 F floats per rank and call - the review's "2 H floats" plus the count) and
+// k_bn_apply_ext merges them in RANK order - every rank the same numbers - before it normalises its own rows.
+__global__ void __launch_bounds__(256) k_bn_local(int64_t n, int F, const float *__restrict__ part, int parts, int64_t rows_per_block, float *tri)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F) return;
+    float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
+    for (int z = 0; z < parts; ++z) {
+        const int64_t r0 = (int64_t)z * rows_per_block;
+        const float nz = (float)((r0 + rows_per_block < n ? r0 + rows_per_block : n) - r0);
+        stats_merge(cnt, mean, m2, nz, part[(size_t)z * 2 * F + j], part[(size_t)z * 2 * F + F + j]);
+    }
+    tri[j] = cnt; tri[F + j] = mean; tri[2 * F + j] = m2;
+}
+
+__global__ void __launch_bounds__(256) k_bn_apply_ext(int64_t n, int F, const float *__restrict__ h, const float *__restrict__ tri_all, int world, float eps,
+                                                      const float *gamma, const float *beta, float *xhat, float *y, float *stats)
+{
+    extern __shared__ float bsh[];
+    float *sm = bsh, *sinv = bsh + F;
+    for (int j = threadIdx.x; j < F; j += blockDim.x) {
+        float cnt = 0.0f, mean = 0.0f, m2 = 0.0f;
+        for (int p = 0; p < world; ++p) stats_merge(cnt, mean, m2, tri_all[(size_t)p * 3 * F + j], tri_all[(size_t)p * 3 * F + F + j], tri_all[(size_t)p * 3 * F + 2 * F + j]);
+        const float var = cnt > 0.0f ? m2 / cnt : 0.0f;
+        sm[j] = mean;
+        sinv[j] = 1.0f / sqrtf(var + eps);
+        if (blockIdx.x == 0) { stats[j] = mean; stats[F + j] = var; }
+    }
+    __syncthreads();
+    const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+        const int j = (int)(i % F);
+        const float xh = (h[i] - sm[j]) * sinv[j];
+        xhat[i] = xh;
+        y[i] = gamma[j] * xh + beta[j];
+    }
+}
+
 // d x = inv / n * (n * dxh - sum dxh - xhat * sum(dxh * xhat)), dxh = d y * gamma, with sum d y * xhat / sum d y added up from the
 // chunk partials p_dyx / p_dy [chunk * pstride + j] (the same numbers k_sum_parts adds into the gamma / beta gradients);
 // then, fused, the derivative of the layer's activation: d <- d x * act'(a) (act < 0: none).  Dynamic LDS: 2 F floats.
@@ -1261,7 +1301,9 @@ inline bool tg_wgrad_covers(int n_in, int n_out) { const int mt = (n_in + 1 + 31
 // Dropout in front of the first Dense layer (rate != 0) is applied on the way out.  The thread of column 0 also evaluates the
 // while-condition of THIS body for its node (reference GNN/GNN.py:202-220: condition(state, state_old), ascending-feature sums as
 // k_check; so == NULL: ones) and raises the body's gate.
+// state: row 0 of the state REPLICA (the sources of the arcs are replica rows); own: the first OWNED row of it (== state on one GPU)
 __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds, int c_aggs, const float *__restrict__ tmpl, const float *__restrict__ state,
+                                                     const float *__restrict__ own,
                                                      const int32_t *__restrict__ indptr, const int32_t *__restrict__ adj_src,
                                                      const float *__restrict__ adj_w, float rate, const uint8_t *mask_in, uint64_t seed, uint8_t *keep,
                                                      float *__restrict__ inp, const float *__restrict__ so, float thr, int *flag)
@@ -1274,7 +1316,7 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
         const int c = (int)(i - r * in_s);
         float v;
         bool skip = false;                         // Ds % 4 == 0: the thread of every fourth aggregate column gathers and writes four
-        if (c < Ds) v = state[r * Ds + c];
+        if (c < Ds) v = own[r * Ds + c];
         else if (c >= c_aggs && c < c_aggs + Ds) {
             const int cc = c - c_aggs;
             v = 0.0f;
@@ -1336,7 +1378,7 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
             if ((Ds & 3) == 0) {
 #pragma unroll 4
                 for (int q = 0; q < Ds; q += 4) {
-                    const float4 sv = *reinterpret_cast<const float4 *>(state + r * Ds + q);
+                    const float4 sv = *reinterpret_cast<const float4 *>(own + r * Ds + q);
                     const float4 ov = so ? *reinterpret_cast<const float4 *>(so + r * Ds + q) : float4{1.0f, 1.0f, 1.0f, 1.0f};
                     const float d0 = sv.x - ov.x, d1 = sv.y - ov.y, d2 = sv.z - ov.z, d3 = sv.w - ov.w;
                     dist = dist + d0 * d0; nrm = nrm + ov.x * ov.x;
@@ -1347,7 +1389,7 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
             } else
                 for (int q = 0; q < Ds; ++q) {
                     const float o = so ? so[r * Ds + q] : 1.0f;
-                    const float df = state[r * Ds + q] - o;
+                    const float df = own[r * Ds + q] - o;
                     dist = dist + df * df;
                     nrm = nrm + o * o;
                 }
@@ -1363,6 +1405,7 @@ __global__ void __launch_bounds__(256) k_train_input(int64_t n, int in_s, int Ds
 // k_train_input gave the condition to the thread of column 0 - a 64-step chain that the other 63 lanes of its wave waited for - and ran
 // one thread per element: 3.2 ms per body at 1 M rows x 135 columns, this one about a quarter of that (profiles/r03_train_c3.txt).
 __global__ void __launch_bounds__(256) k_train_input_rows(int64_t n, int in_s, int Ds, int c_aggs, const float *__restrict__ tmpl, const float *__restrict__ state,
+                                                          const float *__restrict__ own_rows,
                                                           const int32_t *__restrict__ indptr, const int32_t *__restrict__ adj_src,
                                                           const float *__restrict__ adj_w, float *__restrict__ inp)
 {
@@ -1373,7 +1416,7 @@ __global__ void __launch_bounds__(256) k_train_input_rows(int64_t n, int in_s, i
     float *row = inp + r * in_s;
     const int cc = 4 * j;
     if (cc < Ds) {
-        const float4 own = *reinterpret_cast<const float4 *>(state + r * Ds + cc);
+        const float4 own = *reinterpret_cast<const float4 *>(own_rows + r * Ds + cc);
         float4 a4 = {0.0f, 0.0f, 0.0f, 0.0f};
         const int32_t e1 = indptr[r + 1];
         for (int32_t e = indptr[r]; e < e1; e += 4) {
@@ -1639,8 +1682,9 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
 
 // training-mode forward of one Sequential on n rows (x: [n, dims[0]]); *y_out: [n, dims.back()].  keep0 != NULL: the Dropout
 // in front of the first Dense layer has been applied by the producer of x (k_train_input), its mask is keep0.
+// comm != NULL (sharded forward, one process per rank): the BatchNormalization statistics are those of the rows of ALL ranks.
 int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t *keep0, const uint8_t *masks, uint64_t seed, NetCache &c,
-                float **y_out)
+                float **y_out, gnn_comm *comm = nullptr)
 {
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
@@ -1709,7 +1753,25 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
         if ((rc = buf.get(&c.xhat, (size_t)n * F)) || (rc = buf.get(&y, (size_t)n * F))) return rc;
         if (net.calls >= std::max(1, net.max_calls)) return gnn_fail(GNN_ERR_STATE, "more BatchNormalization calls than announced");
         c.stats = net.stats_all + (size_t)net.calls++ * 2 * F;
-        if (n > 0) {
+        if (comm) {
+            // every rank takes part in the exchange, also one without rows (count 0)
+            float *tri = nullptr, *tri_all = nullptr;
+            if ((rc = buf.get(&tri, (size_t)3 * F)) || (rc = buf.get(&tri_all, (size_t)3 * F * comm->world))) return rc;
+            const int64_t rpb = n > 0 ? rows_per_block(n) : 1;
+            const int parts = n > 0 ? (int)cdiv(n, rpb) : 0;
+            float *part = nullptr;
+            if ((rc = buf.get(&part, (size_t)std::max(parts, 1) * 2 * F))) return rc;
+            if (n > 0) {
+                const int cs = column_shift(F);
+                hipLaunchKernelGGL(k_bn_stats, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, h, part, rpb);
+            }
+            hipLaunchKernelGGL(k_bn_local, cdiv(F, 256), 256, 0, st, n, F, part, parts, rpb, tri);
+            HIPCHK(hipGetLastError());
+            if ((rc = gnn_comm_allgather32(comm, tri, tri_all, (size_t)3 * F, st))) return rc;
+            hipLaunchKernelGGL(k_bn_apply_ext, n > 0 ? elementwise_grid(n * F) : 1, 256, sizeof(float) * 2 * F, st, n, F, h, tri_all, comm->world, m->eps, net.gamma,
+                               net.beta, c.xhat, y, c.stats);
+            HIPCHK(hipGetLastError());
+        } else if (n > 0) {
             const int64_t rpb = rows_per_block(n);
             const int parts = (int)cdiv(n, rpb);
             float *part = nullptr;
@@ -2080,7 +2142,15 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
                          const float *bn_state, const float *bn_output, float *k_out, float *out_nodes_host, bool final_sync)
 {
     ARGCHK(l && dropout_state && dropout_output && k_out, "bad arguments");
-    ARGCHK(l->world == 1, "training is single-GPU");
+    // Sharded FORWARD (round 3): node-range shards with full-replica numbering, one process per rank - the state rows are all-gathered
+    // after every body, the BatchNormalization statistics and the iteration gates are those of all ranks.  The backward half is
+    // single-GPU (gnn_loop_train_backward refuses a sharded context).
+    const bool sharded = l->world > 1;
+    gnn_comm *comm = sharded ? l->comm : nullptr;
+    if (sharded) {
+        ARGCHK(l->comm && !l->comm->grp, "training forward on shards: one process per rank (an RCCL communicator), not a loopback group");
+        ARGCHK(!l->g->halo_world && !l->slice_mode && !l->edge_mode, "training forward on shards: node-range shards with full-replica numbering, node- or graph-based");
+    }
     ARGCHK(l->edge_mode == l->edge_expected, "edge-based net_output: call gnn_loop_set_edge_readout first");
     if (!l->have_state0 && l->D) return gnn_fail(GNN_ERR_STATE, "state_vect_dim > 0: call gnn_loop_set_state0 first");
     gnn_graph *g = l->g;
@@ -2119,7 +2189,9 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     float *tmpl = zero_mem + z_s + z_o + z_f;
     // Adjacency by source for the transposed aggregation of the backward pass: the caller's arrays, or (NULL) the graph's
     // own copy, built once from its CSR by destination (a stable counting sort by source keeps destinations ascending)
-    if (src_indptr) {
+    if (sharded) {
+        // (no backward pass on shards: no by-source adjacency)
+    } else if (src_indptr) {
         if ((rc = buf.get(&cx->d_sip, (size_t)N + 1)) || (rc = buf.get(&cx->d_sdst, (size_t)E)) || (rc = buf.get(&cx->d_sw, (size_t)E))) return rc;
         ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E && (E == 0 || (src_dst && src_w)), "bad by-source CSR");
         HIPCHK(hipMemcpy(cx->d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
@@ -2150,7 +2222,7 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, nullptr, g->sh->arc_w, gnn_graph_arc_labels(g), g->AL, g->AL, tmpl + c_agga, in_s, nullptr, 1))) return rc;
     if (l->D) {
         if ((rc = gnn_launch_spmm(st, N, g->sh->indptr, g->sh->adj_src, g->sh->adj_w, g->nodes, g->NL, g->NL, tmpl + c_aggn, in_s, nullptr, 1))) return rc;
-        if ((rc = gnn_launch_copy_cols(st, N, g->NL, g->nodes, g->NL, tmpl + c_nodes, in_s, nullptr, 1))) return rc;
+        if ((rc = gnn_launch_copy_cols(st, N, g->NL, g->nodes + (size_t)g->own_off * g->NL, g->NL, tmpl + c_nodes, in_s, nullptr, 1))) return rc;
     }
     // masks of one iteration of net_state: sum over the dropout positions of N * width bytes
     size_t mask_iter_bytes = 0;
@@ -2174,10 +2246,27 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     // never read.
     int *hflags = static_cast<int *>(arena->host(std::max<size_t>(sizeof(int) * flag_words, 4096)));
     if (!hflags) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
-    std::vector<float *> states;                       // states[i]: the state body i reads; states[0] is read in place
-    states.push_back(const_cast<float *>(l->D ? l->state_init : g->nodes));
+    std::vector<float *> states;                       // states[i]: the state body i reads (row 0 of a replica); states[0] is read in place
+    const size_t own_off = sharded ? (size_t)l->own_off : 0;      // replica row of the first owned row
+    const size_t replica_floats = (size_t)l->N_pad * Ds, shard_floats = (size_t)l->shard_rows * Ds;
+    // owned rows [N, Ds] -> a fresh replica with the rows of all ranks (all-gather in place)
+    auto replicate = [&](const float *own_rows, float **replica) -> int {
+        int r_;
+        if ((r_ = buf.get(replica, replica_floats))) return r_;
+        HIPCHK(hipMemsetAsync(*replica, 0, sizeof(float) * replica_floats, st));        // rows past the last shard's end are never read, but stay finite
+        if (N) HIPCHK(hipMemcpyAsync(*replica + own_off * Ds, own_rows, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+        return gnn_comm_allgather32(comm, *replica + (size_t)l->rank * shard_floats, *replica, shard_floats, st);
+    };
+    if (sharded && l->D) {
+        float *rep0 = nullptr;
+        if ((rc = replicate(l->state_init, &rep0))) return rc;
+        states.push_back(rep0);
+    } else
+        states.push_back(const_cast<float *>(l->D ? l->state_init : g->nodes));      // (D == 0: the node labels, a replica already)
     int enq = 0, k = -1;
-    if (N == 0 || max_iter == 0) k = 0;                // no node can raise a gate / no body allowed
+    if ((!sharded && N == 0) || max_iter == 0) k = 0;  // no node can raise a gate / no body allowed (a rank without rows still follows the others)
+    int *flags_all = nullptr;
+    if (sharded && (rc = buf.get(&flags_all, flag_words * (size_t)l->world))) return rc;
     while (k < 0) {
         const int target = std::min(max_iter, enq + TRAIN_CHUNK);
         for (; enq < target; ++enq) {
@@ -2188,28 +2277,47 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
             if (r0 != 0.0f && (rc = buf.get(&keep0, (size_t)N * in_s))) return rc;
             const uint8_t *mk = d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)enq : nullptr;
             const uint64_t sd = seed + 7919ull * (uint64_t)(enq + 1);
-            if (r0 == 0.0f && (Ds & 3) == 0 && Ds <= 64 && tg_many_rows(N)) {
+            const float *own_cur = states[enq] + own_off * Ds, *own_prev = enq ? states[enq - 1] + own_off * Ds : (const float *)nullptr;
+            if (N == 0) {
+                // (a rank without rows: nothing to compute, it only takes part in the exchanges below)
+            } else if (r0 == 0.0f && (Ds & 3) == 0 && Ds <= 64 && tg_many_rows(N)) {
                 // many rows: the concat 16 lanes per row, gate i = condition(state_i, state_{i-1}) by k_check beside it
-                hipLaunchKernelGGL(k_train_input_rows, cdiv(N * 16, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
+                hipLaunchKernelGGL(k_train_input_rows, cdiv(N * 16, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], own_cur, g->sh->indptr, g->sh->adj_src,
                                    g->sh->adj_w, inp);
                 HIPCHK(hipGetLastError());
-                if ((rc = gnn_launch_check(st, N, Ds, states[enq], enq ? states[enq - 1] : (const float *)nullptr, l->thr, flags + (size_t)enq * GNN_FLAG_WORDS))) return rc;
+                if ((rc = gnn_launch_check(st, N, Ds, own_cur, own_prev, l->thr, flags + (size_t)enq * GNN_FLAG_WORDS))) return rc;
             } else {
                 // the input kernel of body i also evaluates gate i = condition(state_i, state_{i-1})
-                hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], g->sh->indptr, g->sh->adj_src,
-                                   g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp, enq ? states[enq - 1] : (const float *)nullptr, l->thr,
+                hipLaunchKernelGGL(k_train_input, cdiv(N * in_s, 256), 256, 0, st, N, in_s, Ds, c_aggs, tmpl, states[enq], own_cur, g->sh->indptr, g->sh->adj_src,
+                                   g->sh->adj_w, r0, mk, sd + 0x9E37ull, keep0, inp, own_prev, l->thr,
                                    flags + (size_t)enq * GNN_FLAG_WORDS);
                 HIPCHK(hipGetLastError());
             }
             cx->caches.emplace_back();
-            if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y))) return rc;
-            states.push_back(y);
+            if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y, comm))) return rc;
+            if (sharded) {                             // the new rows of all ranks: what the next body gathers from
+                float *rep = nullptr;
+                if ((rc = replicate(y, &rep))) return rc;
+                states.push_back(rep);
+            } else
+                states.push_back(y);
         }
-        HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int) * (size_t)enq * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
+        if (sharded) {                                 // the gates of all ranks (GNN.py:218: reduce_any over ALL nodes)
+            if ((rc = gnn_comm_allgather32(comm, flags, flags_all, flag_words, st))) return rc;
+            HIPCHK(hipMemcpyAsync(hflags, flags_all, sizeof(int) * flag_words, hipMemcpyDeviceToHost, st));     // rank 0's block first; the others below
+        } else
+            HIPCHK(hipMemcpyAsync(hflags, flags, sizeof(int) * (size_t)enq * GNN_FLAG_WORDS, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        std::vector<int> others;
+        if (sharded && l->world > 1) {
+            others.resize(flag_words * (size_t)(l->world - 1));
+            HIPCHK(hipMemcpy(others.data(), flags_all + flag_words, sizeof(int) * others.size(), hipMemcpyDeviceToHost));
+        }
         for (int i = 0; i < enq && k < 0; ++i) {       // gates 0 .. enq - 1 are known; gate enq belongs to the next chunk's first body
             int any = 0;
             for (int w = 0; w < GNN_FLAG_WORDS; w += GNN_FLAG_STRIDE) any |= hflags[(size_t)i * GNN_FLAG_WORDS + w];
+            for (int p = 1; sharded && p < l->world; ++p)
+                for (int w = 0; w < GNN_FLAG_WORDS; w += GNN_FLAG_STRIDE) any |= others[(size_t)(p - 1) * flag_words + (size_t)i * GNN_FLAG_WORDS + w];
             if (!any) k = i;
         }
         if (k < 0 && enq == max_iter) k = max_iter;
@@ -2222,15 +2330,19 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     if (l->edge_mode) {
         if ((rc = gnn_launch_feats_edge(st, l, state, feats))) return rc;
     } else if (M) {
-        hipLaunchKernelGGL(k_gather_feats, cdiv(M * wf, 256), 256, 0, st, M, g->sh->masked_rows, state, Ds, g->nodes, g->NL, NLc, feats);
+        hipLaunchKernelGGL(k_gather_feats, cdiv(M * wf, 256), 256, 0, st, M, g->sh->masked_rows, state + own_off * Ds, Ds, g->nodes + (size_t)g->own_off * g->NL, g->NL, NLc, feats);
         HIPCHK(hipGetLastError());
     }
-    if ((rc = net_forward(st, buf, no_, M, feats, nullptr, d_masks_o, seed + 104729ull, cx->co, &cx->out_nodes))) return rc;
+    if ((rc = net_forward(st, buf, no_, M, feats, nullptr, d_masks_o, seed + 104729ull, cx->co, &cx->out_nodes, comm))) return rc;
     cx->state = state;
     cx->k = k;
     // publish the training-mode state / outputs as the loop's result: gnn_loop_get_state / get_output / readout and
     // gnn_graph_update_labels (LGNN stacking) read them exactly like an inference run's
-    if (N) HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+    if (sharded) {                                     // the whole replica, as after an inference Loop (k == 0 with D == 0: the label rows there are)
+        const size_t have = state == g->nodes ? (size_t)g->nodes_rows * Ds : replica_floats;
+        HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * std::min(have, replica_floats), hipMemcpyDeviceToDevice, st));
+    }
+    else if (N) HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
     if (M) HIPCHK(hipMemcpyAsync(l->out, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemsetAsync(l->kfinal_dev, 0, sizeof(int), st));
     if (out_nodes_host && M) HIPCHK(hipMemcpyAsync(out_nodes_host, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToHost, st));
@@ -2256,6 +2368,7 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
                           float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host, float *d_arcs_host, bool sync)
 {
     ARGCHK(l && grads_state && grads_output, "bad arguments");
+    ARGCHK(l->world == 1, "the backward pass is single-GPU (the sharded training forward, gnn_loop_train_forward on shards, has no backward half yet)");
     TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
     if (!cx || cx->backward_done) return gnn_fail(GNN_ERR_STATE, "gnn_loop_train_forward has not been called (one backward per forward)");
     gnn_graph *g = l->g;
@@ -2496,6 +2609,7 @@ extern "C" int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const
                                    float *bn_batch_state, float *bn_batch_output)
 {
     ARGCHK(l && targets && sample_weights && loss_out && k_out && grads_state && grads_output, "bad arguments");
+    ARGCHK(l->world == 1, "a training step is single-GPU (only the training-mode forward runs on shards: gnn_loop_train_forward)");
     ARGCHK(loss_kind >= 0 && loss_kind <= 2, "loss_kind: 0 categorical_crossentropy, 1 mean_squared_error, 2 categorical_crossentropy(from_logits=True)");
     const int64_t M = l->edge_mode ? l->n_edge_masked : l->g->n_masked;
     const int T = l->T;

@@ -179,6 +179,11 @@ int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *s
  *   gnn_loop_train_forward   training-mode Loop; out_nodes [n_masked, T] (may be NULL) are the node-level outputs.  The
  *                    training-mode state / outputs become the loop's result (gnn_loop_get_state / get_output / readout,
  *                    gnn_graph_update_labels), and the context of the backward pass stays with the loop.
+ *                    On node-range shards with full-replica numbering (one process per rank, an RCCL communicator; round 3) this
+ *                    half also runs sharded: the state rows are all-gathered after every body, and the BatchNormalization batch
+ *                    statistics (reference GNN/MLP.py:62-63, training=True) and the gate of reduce_any (GNN.py:218) are those of
+ *                    the rows of ALL ranks - 3 F floats per rank and BatchNormalization call.  The backward half is single-GPU
+ *                    (GNN_ERR_ARG on a sharded loop).
  *   gnn_loop_train_backward  d_out_nodes [n_masked, T] = d loss / d out_nodes; d_state_extra [N, Ds] (or NULL) = an extra
  *                    gradient on the final state; d_nodes [N, NL] (or NULL) receives d loss / d node labels; d_arc_labels
  *                    [n_arcs, AL] (or NULL; edge-based loops after gnn_graph_set_arc_order) d loss / d arc labels in

@@ -48,6 +48,36 @@ def main():
             res[f'{layout}_{impl}_max'] = np.float64(comm.allreduce_max(float(rank + 1)))
             lp.close()
         comm.close()
+    # ---- training-mode forward on shards (gnn_loop_train_forward with world > 1): state rows all-gathered after every body, the
+    # BatchNormalization statistics and the iteration gates those of all ranks.  Two cases: few rows (per-op kernels) and, MP_TRAIN_WIDE,
+    # the wide-layer path.
+    from util import make_mlp
+    for tag, (nt, dt, hidden, thr_t) in (('train', (1531, 8, (16,), 0.02)), ('trainw', (12000, 64, (128, 128), 0.0))):
+        gt, stt, out_, s0t = S._case(777 + nt, nt, dt, hidden=hidden)
+        rngt = np.random.default_rng(nt)
+        stt = make_mlp(rngt, stt['weights'][0].shape[0], list(hidden) + [dt], 'selu', gain=0.6, bn_random=True)
+        out_ = make_mlp(rngt, out_['weights'][0].shape[0], [2], 'softmax', bn_random=True)
+        stt['dropout'], out_['dropout'] = {}, {}
+        ipt, srct, wt, awt, alt = S._csr_parts(gt)
+        maskt = np.logical_and(gt['set_mask'], gt['output_mask'])
+        os.environ['GNN_BENCH_RDV'] = os.path.join(out_dir, f'id_{tag}')
+        uid, _ = bench.rendezvous_id(rank, world, e)
+        comm = e.Comm(uid, rank, world, 0)
+        mst, mou = e.Mlp(stt['weights'], stt['activations'], True), e.Mlp(out_['weights'], out_['activations'], True)
+        rb, nr, ip, src, w, aw, al_ = e.shard_csr(nt, rank, world, ipt, srct, wt, awt, alt)
+        gr = e.Graph(nt, ip, src, w, aw, al_, gt['nodes'], maskt[rb:rb + nr], row_begin=rb)
+        lp = e.Loop(gr, mst, mou, dt, 4, thr_t, comm)
+        lp.set_state0(s0t[rb:rb + nr])
+        k, outn = lp.train_forward(mst, mou, None, bn_state=np.concatenate(stt['weights'][-4:-2]), bn_output=np.concatenate(out_['weights'][-4:-2]))
+        res[f'{tag}_k'] = np.float64(k)
+        res[f'{tag}_state'] = lp.state()
+        res[f'{tag}_out'] = outn
+        try:
+            lp.train_backward(np.zeros_like(outn))
+            res[f'{tag}_backward_refused'] = np.float64(0)
+        except Exception:
+            res[f'{tag}_backward_refused'] = np.float64(1)
+        lp.close(); comm.close()
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **res)
     print(f'MP_WORKER_OK rank={rank}')
 
