@@ -1150,6 +1150,36 @@ __device__ __forceinline__ void finish_fast64_partial(const GnnFusedArgs &a, flo
         if (4 * u + (lane >> 4) < nvalid) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = *reinterpret_cast<const v4f *>(xs + 4 * u * KP);
 }
 
+// Graph readout of the persistent small-graph loops (k_small_loop / k_small16; reference GNN/GNN.py:331-332, arithmetic of k_readout):
+// out_graph[g, t] = sum over the (node, w) of graph g, ascending, fmaf(w, out[node, t]), one lane per (g, t), by ONE workgroup after the
+// grid barrier behind the output stage.  The entries of a graph are taken eight at a time: their (node, w) pairs are requested
+// together, then the eight output values (sc1 loads: other workgroups wrote them in this launch), then the eight fmaf in stored order -
+// two round trips per eight nodes instead of two per node (a MUTAG graph has 18: 36 dependent round trips were 36 us of a 128 us Loop).
+__device__ __forceinline__ void small_graph_readout(const GnnSmallCtl &c, int lane)
+{
+    for (int t = lane; t < c.G * c.T; t += 64) {
+        const int gi = t / c.T, ci = t - gi * c.T;
+        const int e0 = gload1(c.ng_ip + gi), e1 = gload1(c.ng_ip + gi + 1);
+        float acc = 0.0f;
+        for (int e = e0; e < e1; e += 8) {
+            int node[8];
+            float w[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ee = e + u < e1 ? e + u : e;          // clamp: a real entry, result unused
+                node[u] = gload1(c.ng_node + ee);
+                w[u] = gload1(c.ng_w + ee);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sload1<true>(c.out + (int64_t)node[u] * c.T + ci);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e + u < e1) acc = __builtin_fmaf(w[u], v[u], acc);
+        }
+        c.ng_host[t] = acc;
+    }
+}
+
 // ---- cross-tile prefetch of the dependent loads that open a tile: ticket -> row pointers -> ids of the first gather batch ----
 // Each of them is a full memory round trip in front of the first neighbour row; requested one tile ahead they cost three VGPRs.
 __device__ __forceinline__ int tile_rowptr_request(const GnnFusedArgs &a, int tile, int lane)

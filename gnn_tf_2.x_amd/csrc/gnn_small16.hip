@@ -448,14 +448,7 @@ __global__ void __launch_bounds__(64) k_small16(const GnnFusedArgs a0, const Gnn
     // ---- graph readout (GNN.py:331-332) by workgroup 0 after one more grid barrier; the result goes straight to pinned host memory -----
     if (c.ng_ip) {
         if (arrive_and_gate(c.ro_word, 0) < 0) return;
-        if (blockIdx.x == 0)
-            for (int t = lane; t < c.G * c.T; t += 64) {
-                const int gi = t / c.T, ci = t - gi * c.T;
-                float acc = 0.0f;
-                for (int e = gload1(c.ng_ip + gi); e < gload1(c.ng_ip + gi + 1); ++e)
-                    acc = __builtin_fmaf(gload1(c.ng_w + e), sload1<true>(c.out + (int64_t)gload1(c.ng_node + e) * c.T + ci), acc);
-                c.ng_host[t] = acc;
-            }
+        if (blockIdx.x == 0) small_graph_readout(c, lane);
     }
 }
 
