@@ -118,6 +118,12 @@ __device__ __forceinline__ void small16_layer(const float *b_base, const float (
     if (second) {
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s][1], b[s], acc[1], 0, 0, 0);
+    } else {
+        // The branch around the second chain puts the first chain's last MFMA directly in front of whatever reads acc[0] next, in
+        // another basic block - and hipcc (ROCm 7.2) then inserts no wait states between an 8-pass MFMA and the v_accvgpr_read of its
+        // last destination register: with the linear activation (the read follows at once) feature 3 of every node came out stale
+        // (found by test_persistent_small_graph_loop_random_shapes).  Sixteen wait states here cover the 8-pass result.
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     }
 }
 

@@ -649,6 +649,73 @@ def test_persistent_small_graph_loop(d, nl, al, hidden, act, n):
     assert not big.set_persistent(True)                   # 257 tiles: not all resident at once by the conservative rule
 
 
+def test_persistent_small_graph_loop_random_shapes():
+    """The persistent launch on 30 seeded random shapes (state width 0 / 1 .. 32, label widths, 0 - 2 hidden layers of 1 .. 32 units,
+    every activation, 17 .. 6,000 nodes, sparse and dense rows): k, states and outputs bit-identical to the C oracle.  The tile layout of
+    the kernels depends on all of these (K-steps of layer 0, row stride of the LDS tile, 64- or 128-byte exchange rows, one or two
+    feature tiles in the last layer, arcs per gather round, 16- or 32-node tiles)."""
+    e = _engine()
+    rng = np.random.default_rng(20261004)
+    acts = ['selu', 'tanh', 'relu', 'sigmoid', 'elu', 'linear']
+    for case in range(30):
+        d = int(rng.choice([0, 0, 1, 3, 4, 7, 12, 16, 17, 24, 31, 32]))
+        nl = int(rng.integers(1, 9)) if d else int(rng.integers(1, 33))
+        al = int(rng.integers(1, 5))
+        hidden = tuple(int(x) for x in rng.integers(1, 33, size=int(rng.integers(0, 3))))
+        n = int(rng.choice([17, 33, 100, 640, 1999, 4096, 4097, 6000]))
+        act = acts[case % len(acts)]
+        g, st, ou, s0 = _case(rng, n=n, d=d, nl=nl, al=al, hidden=hidden, act=act, deg=int(rng.choice([1, 4, 11])))
+        mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+        graph = _device_graph(g)
+        max_it, thr = int(rng.integers(1, 12)), float(rng.choice([0.0, 0.01, 0.1]))
+        kc, sc, oc = corc.loop_node(g, st, ou, d, max_it, thr, s0)
+        loop = e.Loop(graph, mst, mou, d, max_it, thr)
+        loop.set_impl(1)
+        if not loop.set_persistent(True):
+            loop.close(); continue
+        if d: loop.set_state0(s0)
+        k = loop.run()
+        assert k == kc and np.array_equal(loop.state(), sc) and np.array_equal(loop.output(), oc), (case, d, nl, al, hidden, n, act, max_it, thr, k, kc)
+        loop.close()
+
+
+def test_fused_kernel_random_shapes():
+    """The per-iteration fused kernel (one launch per body) on 24 seeded random shapes: state widths 0 / 1 .. 64, label widths, 0 - 2
+    hidden layers of 1 .. 128 units, every activation, partial last tiles, sparse and dense rows.  impl 1 bit-identical to the C oracle,
+    impl 2 (split arithmetic) same k or one body apart at a borderline threshold, and within tolerance when k agrees."""
+    e = _engine()
+    rng = np.random.default_rng(20261005)
+    acts = ['selu', 'tanh', 'relu', 'sigmoid', 'elu', 'linear']
+    ran = 0
+    for case in range(24):
+        d = int(rng.choice([0, 1, 4, 8, 12, 20, 32, 40, 60, 64]))
+        nl = int(rng.integers(1, 9)) if d else int(rng.choice([1, 3, 8, 16, 33, 64]))
+        al = int(rng.integers(1, 5))
+        hidden = tuple(int(x) for x in rng.choice([1, 7, 16, 31, 32, 33, 64, 96, 128], size=int(rng.integers(0, 3))))
+        n = int(rng.choice([31, 32, 257, 1000, 3000]))
+        act = acts[case % len(acts)]
+        g, st, ou, s0 = _case(rng, n=n, d=d, nl=nl, al=al, hidden=hidden, act=act, gain=0.5, deg=int(rng.choice([1, 4, 11])))
+        mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+        max_it, thr = int(rng.integers(1, 9)), float(rng.choice([0.0, 0.01]))
+        kc, sc, oc = corc.loop_node(g, st, ou, d, max_it, thr, s0)
+        loop = e.Loop(_device_graph(g), mst, mou, d, max_it, thr)
+        if loop.set_impl(1) != 1:
+            loop.close(); continue                      # shape outside the fused kernel (covered by test_wide_states_and_fallback)
+        loop.set_persistent(False)
+        if d: loop.set_state0(s0)
+        k = loop.run()
+        assert k == kc and np.array_equal(loop.state(), sc) and np.array_equal(loop.output(), oc), (case, d, nl, al, hidden, n, act, max_it, thr, k, kc)
+        assert loop.set_impl(2) == 2
+        k2 = loop.run()
+        assert abs(k2 - kc) <= 1, (case, k2, kc)
+        if k2 == kc:
+            err = float(np.max(np.abs(loop.state() - sc)))
+            assert err < 1e-5 * max(1.0, float(np.max(np.abs(sc)))), (case, d, nl, al, hidden, n, act, max_it, thr, err)
+        loop.close()
+        ran += 1
+    assert ran >= 12
+
+
 def test_lgnn_run_in_one_call_and_work_counters():
     """gnn_lgnn_run = LGNN.Loop (reference LGNN.py:263-290) of a whole stack through ONE C-ABI call: layer i on graphs[i], relabelling
     from the ORIGINAL graph in between; bit-identical to the C oracle chain.  gnn_counters_get: the algorithmic work of one iteration."""
