@@ -118,3 +118,21 @@ def test_bench_launcher_runs_all_ranks_end_to_end(gpus, exchange):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == gpus and line['steps'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own invocation for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the agent; the RCCL id through a file keyed by the
+    agent's pid and the port).  Two ranks on device 0 over the stand-in transport, a reduced graph."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, GNN_RCCL_LIBRARY=_mock(), GNN_BENCH_ONE_DEVICE='1', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'GNN_BENCH_RDV'): env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--nodes', '60000', '--no-cpu-baseline', '--no-other-configs']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'strong' and line['value'] > 0
