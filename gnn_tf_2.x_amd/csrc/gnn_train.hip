@@ -203,6 +203,17 @@ __global__ void __launch_bounds__(256) k_sum_parts(int parts, int64_t count, con
     sum_parts_block(blockIdx.x, parts, count, part, out, sp);
 }
 
+// out[j] = sum over the chunks z (ascending) of base[z * stride + j], j < count: a rank's own share of sums that the sharded backward
+// pass exchanges (BatchNormalization: sum d y xhat | sum d y)
+__global__ void __launch_bounds__(256) k_sum_strided(int parts, int64_t stride, const float *__restrict__ base, int count, float *out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    float acc = 0.0f;
+    for (int z = 0; z < parts; ++z) acc += base[(size_t)z * stride + j];
+    out[j] = acc;
+}
+
 // BatchNormalization, training mode, forward statistics of one row chunk: part[chunk][j] = chunk mean, part[chunk][F + j] =
 // sum over the chunk of (x - chunk mean)^2 (two passes over the chunk's rows)
 __global__ void __launch_bounds__(256) k_bn_stats(int64_t n, int F, int cw_shift, const float *__restrict__ h, float *part, int64_t rows_per_block)
@@ -353,8 +364,9 @@ __global__ void __launch_bounds__(256) k_bn_apply_ext(int64_t n, int F, const fl
 // then, fused, the derivative of the layer's activation: d <- d x * act'(a) (act < 0: none).  Dynamic LDS: 2 F floats.
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_shift, float *d, const float *__restrict__ xhat, const float *gamma,
                                                       const float *stats, float eps, const float *__restrict__ p_dyx, const float *__restrict__ p_dy,
-                                                      int64_t pstride, int parts, const float *__restrict__ a, int act)
+                                                      int64_t pstride, int parts, const float *__restrict__ a, int act, int64_t n_stat = 0)
 {
+    // n_stat: rows the batch statistics were taken over (sharded backward: the rows of ALL ranks, the partial sums are then one pair per rank); 0: n
     extern __shared__ float bsh[];
     __shared__ float sc[2][256];
     float *s_dyx = bsh, *s_dy = bsh + F;
@@ -376,7 +388,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_s
         __syncthreads();
     }
     const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
-    const float m = (float)n;
+    const float m = (float)(n_stat > 0 ? n_stat : n);
     const bool small = total < ((int64_t)1 << 31);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
         const int j = small ? (int)((unsigned)i % (unsigned)F) : (int)(i % F);
@@ -1799,13 +1811,23 @@ struct StateGradJob {
 
 // back-propagation through one Sequential: d is d loss / d y on entry ([n, dims.back()], overwritten); on return *dx_out is
 // d loss / d x ([n, dims[0]]); weight gradients are ADDED into net.grads (one sum over the call's chunk partials)
-int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d, float **dx_out, const StateGradJob *job = nullptr)
+// comm != NULL (sharded backward, one process per rank): the sums of BatchNormalization's backward pass are those of the rows of ALL
+// ranks (n_global of them); the weight gradients stay this rank's share (train_backward adds the shares up at the end).
+int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d, float **dx_out, const StateGradJob *job = nullptr,
+                 gnn_comm *comm = nullptr, int64_t n_global = 0)
 {
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
     const int64_t n = c.n;
     int rc;
     if (n <= 0) {                              // no rows: no gradient; d x is empty
+        if (comm && m->has_bn) {               // ... but the other ranks wait for this one's (zero) share of the sums
+            const int F = m->dims.back();
+            float *loc = nullptr, *all = nullptr;
+            if ((rc = buf.get(&loc, (size_t)2 * F)) || (rc = buf.get(&all, (size_t)2 * F * comm->world))) return rc;
+            HIPCHK(hipMemsetAsync(loc, 0, sizeof(float) * 2 * F, st));
+            if ((rc = gnn_comm_allgather32(comm, loc, all, (size_t)2 * F, st))) return rc;
+        }
         *dx_out = d;
         return GNN_OK;
     }
@@ -1824,8 +1846,19 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         float *p_dyx = net.part + net.g_off[2 * L], *p_dy = net.part + net.g_off[2 * L + 1];
         const bool fuse = net.rate[L] == 0.0f && act_last != GNN_ACT_SOFTMAX;
         hipLaunchKernelGGL(k_colreduce2, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, d, c.xhat, p_dyx, p_dy, ps, rpb);
-        hipLaunchKernelGGL(k_bn_bwd_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps,
-                           p_dyx, p_dy, ps, parts, c.a[L - 1], fuse ? act_last : -1);
+        if (comm) {
+            // this rank's sums [sum d y xhat | sum d y] (adjacent in the gradient vector: they ARE the gamma / beta gradients), those of
+            // all ranks all-gathered, added in rank order by every block of the apply kernel
+            float *loc = nullptr, *all = nullptr;
+            if ((rc = buf.get(&loc, (size_t)2 * F)) || (rc = buf.get(&all, (size_t)2 * F * comm->world))) return rc;
+            hipLaunchKernelGGL(k_sum_strided, cdiv(2 * F, 256), 256, 0, st, parts, ps, p_dyx, 2 * F, loc);
+            HIPCHK(hipGetLastError());
+            if ((rc = gnn_comm_allgather32(comm, loc, all, (size_t)2 * F, st))) return rc;
+            hipLaunchKernelGGL(k_bn_bwd_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps,
+                               all, all + F, (int64_t)2 * F, comm->world, c.a[L - 1], fuse ? act_last : -1, n_global);
+        } else
+            hipLaunchKernelGGL(k_bn_bwd_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps,
+                               p_dyx, p_dy, ps, parts, c.a[L - 1], fuse ? act_last : -1, (int64_t)0);
         HIPCHK(hipGetLastError());
         last_act_done = fuse;
     }
@@ -2100,6 +2133,7 @@ struct TrainCtx {
     float *state = nullptr, *out_nodes = nullptr;
     int k = 0;
     int64_t N = 0, M = 0;
+    int64_t N_global = 0, M_global = 0;   // sharded forward: the rows / masked rows of all ranks
     bool backward_done = false;   // the gradients are complete (and the activations spent)
     bool applied = false;         // gnn_loop_optimizer_step has consumed them
 };
@@ -2137,14 +2171,26 @@ extern "C" int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const flo
 
 
 // Training-mode Loop.  final_sync: wait for the published state / outputs (and out_nodes_host) before returning.
+// owned rows [n_rows, Ds] -> a fresh replica [N_pad, Ds] with the rows of all ranks (all-gather in place); sharded training only
+static int train_replicate(gnn_loop *l, Buf &buf, hipStream_t st, const float *own_rows, float **replica)
+{
+    const int Ds = l->Ds;
+    const size_t replica_floats = (size_t)l->N_pad * Ds, shard_floats = (size_t)l->shard_rows * Ds;
+    int rc;
+    if ((rc = buf.get(replica, replica_floats))) return rc;
+    HIPCHK(hipMemsetAsync(*replica, 0, sizeof(float) * replica_floats, st));        // rows past the last shard's end are never read, but stay finite
+    if (l->g->n_rows) HIPCHK(hipMemcpyAsync(*replica + (size_t)l->own_off * Ds, own_rows, sizeof(float) * (size_t)l->g->n_rows * Ds, hipMemcpyDeviceToDevice, st));
+    return gnn_comm_allgather32(l->comm, *replica + (size_t)l->rank * shard_floats, *replica, shard_floats, st);
+}
+
 static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w, const float *dropout_state,
                          const float *dropout_output, const uint8_t *masks_state, const uint8_t *masks_output, uint64_t seed,
                          const float *bn_state, const float *bn_output, float *k_out, float *out_nodes_host, bool final_sync)
 {
     ARGCHK(l && dropout_state && dropout_output && k_out, "bad arguments");
     // Sharded FORWARD (round 3): node-range shards with full-replica numbering, one process per rank - the state rows are all-gathered
-    // after every body, the BatchNormalization statistics and the iteration gates are those of all ranks.  The backward half is
-    // single-GPU (gnn_loop_train_backward refuses a sharded context).
+    // after every body, the BatchNormalization statistics and the iteration gates are those of all ranks.  gnn_loop_train_backward
+    // continues on the shards when the by-source adjacency of the owned rows was given here.
     const bool sharded = l->world > 1;
     gnn_comm *comm = sharded ? l->comm : nullptr;
     if (sharded) {
@@ -2190,7 +2236,25 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     // Adjacency by source for the transposed aggregation of the backward pass: the caller's arrays, or (NULL) the graph's
     // own copy, built once from its CSR by destination (a stable counting sort by source keeps destinations ascending)
     if (sharded) {
-        // (no backward pass on shards: no by-source adjacency)
+        // the backward pass on shards needs the arcs that LEAVE the owned rows (by-source CSR over the owned rows, destinations as
+        // replica rows): the caller's arrays, or none - gnn_loop_train_backward is then refused
+        if (src_indptr) {
+            const int64_t Es = src_indptr[N];
+            ARGCHK(src_indptr[0] == 0 && Es >= 0 && (Es == 0 || (src_dst && src_w)), "bad by-source CSR");
+            if ((rc = buf.get(&cx->d_sip, (size_t)N + 1)) || (rc = buf.get(&cx->d_sdst, (size_t)std::max<int64_t>(Es, 1))) || (rc = buf.get(&cx->d_sw, (size_t)std::max<int64_t>(Es, 1)))) return rc;
+            HIPCHK(hipMemcpy(cx->d_sip, src_indptr, sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
+            if (Es) { HIPCHK(hipMemcpy(cx->d_sdst, src_dst, sizeof(int32_t) * Es, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(cx->d_sw, src_w, sizeof(float) * Es, hipMemcpyHostToDevice)); }
+        }
+        // rows and masked rows of all ranks (BatchNormalization's backward pass divides by them)
+        int *cnt = nullptr, *cnt_all = nullptr;
+        if ((rc = buf.get(&cnt, (size_t)4)) || (rc = buf.get(&cnt_all, (size_t)4 * l->world))) return rc;
+        const int mine[4] = {(int)N, (int)M, 0, 0};
+        HIPCHK(hipMemcpy(cnt, mine, sizeof(mine), hipMemcpyHostToDevice));
+        if ((rc = gnn_comm_allgather32(comm, cnt, cnt_all, 4, st))) return rc;
+        std::vector<int> all((size_t)4 * l->world);
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(all.data(), cnt_all, sizeof(int) * all.size(), hipMemcpyDeviceToHost));
+        for (int p = 0; p < l->world; ++p) { cx->N_global += all[(size_t)4 * p]; cx->M_global += all[(size_t)4 * p + 1]; }
     } else if (src_indptr) {
         if ((rc = buf.get(&cx->d_sip, (size_t)N + 1)) || (rc = buf.get(&cx->d_sdst, (size_t)E)) || (rc = buf.get(&cx->d_sw, (size_t)E))) return rc;
         ARGCHK(src_indptr[0] == 0 && src_indptr[N] == E && (E == 0 || (src_dst && src_w)), "bad by-source CSR");
@@ -2248,15 +2312,8 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     if (!hflags) return gnn_fail(GNN_ERR_HIP, "hipHostMalloc failed");
     std::vector<float *> states;                       // states[i]: the state body i reads (row 0 of a replica); states[0] is read in place
     const size_t own_off = sharded ? (size_t)l->own_off : 0;      // replica row of the first owned row
-    const size_t replica_floats = (size_t)l->N_pad * Ds, shard_floats = (size_t)l->shard_rows * Ds;
-    // owned rows [N, Ds] -> a fresh replica with the rows of all ranks (all-gather in place)
-    auto replicate = [&](const float *own_rows, float **replica) -> int {
-        int r_;
-        if ((r_ = buf.get(replica, replica_floats))) return r_;
-        HIPCHK(hipMemsetAsync(*replica, 0, sizeof(float) * replica_floats, st));        // rows past the last shard's end are never read, but stay finite
-        if (N) HIPCHK(hipMemcpyAsync(*replica + own_off * Ds, own_rows, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
-        return gnn_comm_allgather32(comm, *replica + (size_t)l->rank * shard_floats, *replica, shard_floats, st);
-    };
+    const size_t replica_floats = (size_t)l->N_pad * Ds;
+    auto replicate = [&](const float *own_rows, float **replica) -> int { return train_replicate(l, buf, st, own_rows, replica); };
     if (sharded && l->D) {
         float *rep0 = nullptr;
         if ((rc = replicate(l->state_init, &rep0))) return rc;
@@ -2368,9 +2425,18 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
                           float *grads_output, float *bn_batch_state, float *bn_batch_output, float *d_nodes_host, float *d_arcs_host, bool sync)
 {
     ARGCHK(l && grads_state && grads_output, "bad arguments");
-    ARGCHK(l->world == 1, "the backward pass is single-GPU (the sharded training forward, gnn_loop_train_forward on shards, has no backward half yet)");
     TrainCtx *cx = static_cast<TrainCtx *>(l->train_ctx);
     if (!cx || cx->backward_done) return gnn_fail(GNN_ERR_STATE, "gnn_loop_train_forward has not been called (one backward per forward)");
+    // Sharded backward (round 3; after a sharded gnn_loop_train_forward that was given the by-source adjacency of the owned rows): per
+    // body the gradient of the aggregated-state columns is all-gathered like the state in the forward pass and every rank adds up, for
+    // its own rows, what its out-arcs carry back; BatchNormalization's sums are those of all ranks; at the end the ranks' shares of the
+    // weight gradients are all-gathered and added in rank order, so every rank returns the same, complete gradients.
+    const bool sharded = l->world > 1;
+    gnn_comm *comm = sharded ? l->comm : nullptr;
+    if (sharded) {
+        ARGCHK(cx->d_sip, "backward on shards: gnn_loop_train_forward needs the by-source adjacency of the owned rows (src_indptr / src_dst / src_w)");
+        ARGCHK(!d_state_extra && !d_nodes_host && !d_arcs_host && !l->edge_mode, "backward on shards: no extra state gradient, label or arc-label gradients, node- or graph-based only");
+    }
     gnn_graph *g = l->g;
     const int64_t N = g->n_rows, M = l->edge_mode ? l->n_edge_masked : g->n_masked;
     const int Ds = l->Ds, NLc = l->NLc, in_s = l->in_s, T = l->T, wf = l->ou->dims[0], NL = g->NL, k = cx->k;
@@ -2384,7 +2450,7 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
     float *d_out = d_out_dev, *d_feats = nullptr, *d_state = nullptr, *tmp = nullptr, *d_nodes = nullptr, *via = nullptr;
     if ((!d_out && (rc = buf.get(&d_out, (size_t)M * T))) || (rc = buf.get(&d_state, (size_t)N * Ds))) return rc;
     if (!d_out_dev && M) HIPCHK(hipMemcpyAsync(d_out, d_out_host, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, st));
-    if ((rc = net_backward(st, buf, no_, cx->co, d_out, &d_feats))) return rc;
+    if ((rc = net_backward(st, buf, no_, cx->co, d_out, &d_feats, nullptr, comm, cx->M_global))) return rc;
     if (d_state_extra) { if (N) HIPCHK(hipMemcpyAsync(d_state, d_state_extra, sizeof(float) * (size_t)N * Ds, hipMemcpyHostToDevice, st)); }
     else HIPCHK(hipMemsetAsync(d_state, 0, sizeof(float) * std::max<size_t>(1, (size_t)N * Ds), st));
     const bool want_nodes = d_nodes_host != nullptr;
@@ -2427,8 +2493,22 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
         // net_backward consumes d_state (d loss / d state_{it+1}) in place; its last launch also writes d loss / d state_it into a new buffer
         float *d_inp = nullptr, *d_prev = nullptr;
         if ((rc = buf.get(&d_prev, (size_t)N * Ds))) return rc;
-        const StateGradJob job{N, Ds, in_s, c_aggs, cx->d_sip, cx->d_sdst, cx->d_sw, d_prev};
-        if ((rc = net_backward(st, buf, ns, cx->caches[it], d_state, &d_inp, &job))) return rc;
+        if (sharded) {
+            if ((rc = net_backward(st, buf, ns, cx->caches[it], d_state, &d_inp, nullptr, comm, cx->N_global))) return rc;
+            // d state_it[r] = d inp[r, :Ds] + sum over the arcs r -> dst of w * d inp[dst, c_aggs:]: the aggregate columns of all ranks first
+            float *dagg = nullptr, *rep = nullptr;
+            if ((rc = buf.get(&dagg, (size_t)std::max<int64_t>(N, 1) * Ds))) return rc;
+            if (N && (rc = gnn_launch_copy_cols(st, N, Ds, d_inp + c_aggs, in_s, dagg, Ds, nullptr, 1))) return rc;
+            if ((rc = train_replicate(l, buf, st, dagg, &rep))) return rc;
+            if (N) {
+                if ((rc = gnn_launch_spmm(st, N, cx->d_sip, cx->d_sdst, cx->d_sw, rep, Ds, Ds, d_prev, Ds, nullptr, 1))) return rc;
+                hipLaunchKernelGGL(k_add_cols, cdiv(N * Ds, 256), 256, 0, st, N, Ds, d_inp, in_s, 0, d_prev);
+                HIPCHK(hipGetLastError());
+            }
+        } else {
+            const StateGradJob job{N, Ds, in_s, c_aggs, cx->d_sip, cx->d_sdst, cx->d_sw, d_prev};
+            if ((rc = net_backward(st, buf, ns, cx->caches[it], d_state, &d_inp, &job))) return rc;
+        }
         d_state = d_prev;
         if (want_arcs && N) {
             hipLaunchKernelGGL(k_add_cols, cdiv(N * AL, 256), 256, 0, st, N, AL, d_inp, in_s, c_agga, d_aa);
@@ -2437,6 +2517,16 @@ static int train_backward(gnn_loop *l, float *d_out_dev, const float *d_out_host
         if (want_nodes && l->D && N) {    // labels enter each body directly and through aggregated_nodes (GNN.py:228, :263)
             if ((rc = gnn_launch_spmm(st, N, cx->d_sip, cx->d_sdst, cx->d_sw, d_inp + c_aggn, NL, in_s, via, NL, nullptr, 1))) return rc;
             hipLaunchKernelGGL(k_nodes_grad, cdiv(N * NL, 256), 256, 0, st, N, NL, d_inp, in_s, c_nodes, via, d_nodes);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (sharded) {          // the ranks' shares of the weight gradients -> their sum in rank order, on every rank (and in place: gnn_loop_optimizer_step reads it)
+        for (Net *net : {&ns, &no_}) {
+            float *all = nullptr;
+            if ((rc = buf.get(&all, net->g_total * (size_t)l->world))) return rc;
+            if ((rc = gnn_comm_allgather32(comm, net->grads, all, net->g_total, st))) return rc;
+            HIPCHK(hipMemsetAsync(net->grads, 0, sizeof(float) * net->g_total, st));
+            hipLaunchKernelGGL(k_sum_parts, cdiv((int64_t)net->g_total, 64), 256, 0, st, l->world, (int64_t)net->g_total, all, net->grads);
             HIPCHK(hipGetLastError());
         }
     }

@@ -182,12 +182,17 @@ int gnn_loop_train_step(gnn_loop *l, const int32_t *src_indptr, const int32_t *s
  *                    On node-range shards with full-replica numbering (one process per rank, an RCCL communicator; round 3) this
  *                    half also runs sharded: the state rows are all-gathered after every body, and the BatchNormalization batch
  *                    statistics (reference GNN/MLP.py:62-63, training=True) and the gate of reduce_any (GNN.py:218) are those of
- *                    the rows of ALL ranks - 3 F floats per rank and BatchNormalization call.  The backward half is single-GPU
- *                    (GNN_ERR_ARG on a sharded loop).
+ *                    the rows of ALL ranks - 3 F floats per rank and BatchNormalization call.  Give src_indptr / src_dst / src_w = the
+ *                    arcs that LEAVE the owned rows (CSR over the owned rows, destinations as replica rows) for the backward half.
  *   gnn_loop_train_backward  d_out_nodes [n_masked, T] = d loss / d out_nodes; d_state_extra [N, Ds] (or NULL) = an extra
  *                    gradient on the final state; d_nodes [N, NL] (or NULL) receives d loss / d node labels; d_arc_labels
  *                    [n_arcs, AL] (or NULL; edge-based loops after gnn_graph_set_arc_order) d loss / d arc labels in
- *                    ORIGINAL arc order (LGNN.py:253-254).  One backward per forward.
+ *                    ORIGINAL arc order (LGNN.py:253-254).  One backward per forward.  On shards (after a sharded forward that was
+ *                    given the by-source adjacency; node- / graph-based, no d_state_extra / d_nodes / d_arc_labels): per body the
+ *                    gradient of the aggregated-state columns is all-gathered and every rank sums what its out-arcs carry back, the
+ *                    sums of BatchNormalization's backward pass are those of all ranks, and the ranks' shares of the weight
+ *                    gradients are added in rank order - every rank returns the same, complete gradients.  gnn_loop_train_step (one
+ *                    call with the loss inside) stays single-GPU.
  *   gnn_loss_grad    host helper: *loss = sum_i w_i L(t_i, out_i) and d_out = d loss / d out (may be NULL). */
 int gnn_loop_train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *src_dst, const float *src_w,
                            const float *dropout_state, const float *dropout_output, const uint8_t *masks_state,

@@ -55,7 +55,7 @@ def main():
     for tag, (nt, dt, hidden, thr_t) in (('train', (1531, 8, (16,), 0.02)), ('trainw', (12000, 64, (128, 128), 0.0))):
         gt, stt, out_, s0t = S._case(777 + nt, nt, dt, hidden=hidden)
         rngt = np.random.default_rng(nt)
-        stt = make_mlp(rngt, stt['weights'][0].shape[0], list(hidden) + [dt], 'selu', gain=0.6, bn_random=True)
+        stt = make_mlp(rngt, stt['weights'][0].shape[0], list(hidden) + [dt], 'selu' if tag == 'train' else 'tanh', gain=0.6, bn_random=True)      # (wide case: a smooth activation - SELU's kink makes single gradient entries jump)
         out_ = make_mlp(rngt, out_['weights'][0].shape[0], [2], 'softmax', bn_random=True)
         stt['dropout'], out_['dropout'] = {}, {}
         ipt, srct, wt, awt, alt = S._csr_parts(gt)
@@ -68,15 +68,25 @@ def main():
         gr = e.Graph(nt, ip, src, w, aw, al_, gt['nodes'], maskt[rb:rb + nr], row_begin=rb)
         lp = e.Loop(gr, mst, mou, dt, 4, thr_t, comm)
         lp.set_state0(s0t[rb:rb + nr])
-        k, outn = lp.train_forward(mst, mou, None, bn_state=np.concatenate(stt['weights'][-4:-2]), bn_output=np.concatenate(out_['weights'][-4:-2]))
+        # the arcs that LEAVE the owned rows (by-source CSR of the whole graph, rows rb .. rb + nr; destinations stay global ids)
+        from test_gpu_train import _by_source_csr
+        sip, sdst, sw = _by_source_csr(gt, nt)
+        own = (sip[rb:rb + nr + 1] - sip[rb]).astype(np.int32), sdst[sip[rb]:sip[rb + nr]], sw[sip[rb]:sip[rb + nr]]
+        k, outn = lp.train_forward(mst, mou, own, bn_state=np.concatenate(stt['weights'][-4:-2]), bn_output=np.concatenate(out_['weights'][-4:-2]))
         res[f'{tag}_k'] = np.float64(k)
         res[f'{tag}_state'] = lp.state()
         res[f'{tag}_out'] = outn
-        try:
-            lp.train_backward(np.zeros_like(outn))
-            res[f'{tag}_backward_refused'] = np.float64(0)
-        except Exception:
-            res[f'{tag}_backward_refused'] = np.float64(1)
+        # loss over the masked rows of ALL ranks: targets / weights of the whole graph drawn alike on every rank, this rank's rows of them
+        m_all = int(maskt.sum())
+        rngl = np.random.default_rng(99)
+        targets = np.eye(2)[rngl.integers(0, 2, m_all)].astype(np.float32)
+        weights = (rngl.uniform(0.5, 1.5, m_all) / m_all).astype(np.float32)
+        m0 = int(maskt[:rb].sum())
+        loss, d_out = e.loss_grad(0, targets[m0:m0 + outn.shape[0]], outn, weights[m0:m0 + outn.shape[0]])
+        back = lp.train_backward(d_out)
+        res[f'{tag}_loss'] = np.float64(loss)
+        for i, garr in enumerate(back['grads_state']): res[f'{tag}_gs{i}'] = garr
+        for i, garr in enumerate(back['grads_output']): res[f'{tag}_go{i}'] = garr
         lp.close(); comm.close()
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **res)
     print(f'MP_WORKER_OK rank={rank}')

@@ -39,8 +39,9 @@ def _env(rank, world, extra=None):
 @pytest.mark.parametrize('world', [2, 4])
 def test_ranks_as_processes_match_oracle(world):
     """world processes, every exchange layout, impl 1 bit-identical to the C oracle (k, states, outputs), impl 2 within tolerance; then the
-    training-mode forward on shards (state all-gather per body, BatchNormalization statistics and gates of all ranks) against the float64
-    oracle and the one-GPU forward."""
+    training step on shards - forward (state all-gather per body, BatchNormalization statistics and gates of all ranks) and backward (the
+    aggregate-column gradients all-gathered per body, BatchNormalization sums of all ranks, the ranks' weight-gradient shares added in rank
+    order) - against the float64 oracle and the one-GPU forward."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import test_gpu_sharded as S
     n, d = 4099, 8
@@ -81,7 +82,7 @@ def test_ranks_as_processes_match_oracle(world):
     for tag, (nt, dt, hidden, thr_t) in (('train', (1531, 8, (16,), 0.02)), ('trainw', (12000, 64, (128, 128), 0.0))):
         gt, stt, out_, s0t = S._case(777 + nt, nt, dt, hidden=hidden)
         rngt = np.random.default_rng(nt)
-        stt = make_mlp(rngt, stt['weights'][0].shape[0], list(hidden) + [dt], 'selu', gain=0.6, bn_random=True)
+        stt = make_mlp(rngt, stt['weights'][0].shape[0], list(hidden) + [dt], 'selu' if tag == 'train' else 'tanh', gain=0.6, bn_random=True)      # (wide case: a smooth activation - SELU's kink makes single gradient entries jump)
         out_ = make_mlp(rngt, out_['weights'][0].shape[0], [2], 'softmax', bn_random=True)
         stt['dropout'], out_['dropout'] = {}, {}
         ctx = tro.train_forward(gt, stt, out_, dt, 4, thr_t, s0t, [{}] * 4, {})
@@ -103,7 +104,20 @@ def test_ranks_as_processes_match_oracle(world):
         k1, out1 = lp.train_forward(mst, mou, None, bn_state=np.concatenate(stt['weights'][-4:-2]), bn_output=np.concatenate(out_['weights'][-4:-2]))
         so_ = max(1.0, float(np.max(np.abs(out1))))
         assert k1 == ctx['k'] and np.max(np.abs(lp.state() - state)) < 2e-5 * scale and np.max(np.abs(out1 - outp)) < 2e-5 * so_
-        assert all(float(r[f'{tag}_backward_refused']) == 1.0 for r in res)        # no backward half on shards (yet): refused, not wrong
+        # ---- the backward half on the shards: every rank returns the same, complete gradients; against the float64 oracle's step
+        m_all = int(maskt.sum())
+        rngl = np.random.default_rng(99)
+        targets = np.eye(2)[rngl.integers(0, 2, m_all)].astype(np.float32)
+        weights = (rngl.uniform(0.5, 1.5, m_all) / m_all).astype(np.float32)
+        ref = tro.train_step(gt, stt, out_, dt, 4, thr_t, s0t, [{}] * 4, {}, targets, weights, loss='categorical_crossentropy', mean=False, graph_based=False)
+        assert abs(sum(float(r[f'{tag}_loss']) for r in res) - ref['loss']) < 1e-5 * max(1.0, abs(ref['loss']))
+        gscale = max(float(np.max(np.abs(w_))) for w_ in ref['grads_state'])
+        for name, wl in (('gs', ref['grads_state']), ('go', ref['grads_output'])):
+            for i, want in enumerate(wl):
+                got = [r[f'{tag}_{name}{i}'] for r in res]
+                assert all(np.array_equal(got[0], x) for x in got[1:]), (tag, name, i)          # the same bits on every rank
+                tol = 1e-3 * max(float(np.max(np.abs(want))), 0.1 * gscale)
+                assert got[0].shape == want.shape and np.max(np.abs(got[0] - want)) < tol, (tag, name, i, float(np.max(np.abs(got[0] - want))), tol)
 
 
 @pytest.mark.parametrize('gpus,exchange', [(2, 'auto'), (4, 'auto'), (3, 'halo')])
