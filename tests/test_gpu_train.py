@@ -652,3 +652,52 @@ def test_wide_layers_on_the_matrix_cores_match_oracle(n, with_dropout):
         assert np.max(np.abs(got - want)) <= tol * max(0.1 * scale, np.max(np.abs(want))), (got.shape, np.max(np.abs(got - want)), np.max(np.abs(want)), scale)
     for a, b in zip(runs[0]['grads_state'] + runs[0]['grads_output'], runs[1]['grads_state'] + runs[1]['grads_output']):
         assert np.array_equal(a, b)
+
+
+def test_train_step_random_shapes():
+    """gnn_loop_train_step on 14 seeded random shapes (state width 0 / 1 .. 64, 0 - 2 hidden layers of 1 .. 128 units, smooth activations -
+    the kinks of relu / selu make single gradient entries jump between float32 and float64, DESIGN.md section 7 - with and without
+    BatchNormalization, 40 .. 9,000 nodes so that both the per-op and the matrix-core kernels take part): k, loss and every gradient array
+    against the float64 oracle, and identical bits on a repeated step."""
+    from GNN import _engine as e
+    rng = np.random.default_rng(20261006)
+    for case in range(14):
+        d = int(rng.choice([0, 1, 4, 8, 16, 33, 64]))
+        nl = int(rng.integers(1, 6)) if d else int(rng.choice([2, 7, 16]))
+        al = int(rng.integers(1, 4))
+        hidden = [int(x) for x in rng.choice([1, 9, 32, 64, 100, 128], size=int(rng.integers(0, 3)))]
+        n = int(rng.choice([40, 333, 2000, 5000, 9000]))
+        act = ['tanh', 'sigmoid', 'linear'][case % 3]
+        bn = bool(case % 4 != 3)
+        max_it = int(rng.integers(1, 5))
+        arcs = random_arcs(rng, n, int(rng.choice([1, 3, 8])) * n, al)
+        nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+        g = orc.make_graph_dict(arcs, nodes, str(rng.choice(['average', 'sum', 'normalized'])))
+        g['set_mask'] = rng.random(n) < 0.7
+        ds, nlc = (d if d else nl), (nl if d else 0)
+        st = make_mlp(rng, al + 2 * (ds + nlc), hidden + [ds], act, gain=0.5, bn_random=True, batch_normalization=bn)
+        ou = make_mlp(rng, ds + nlc, [2], 'softmax', batch_normalization=False)      # (BatchNormalization behind a softmax leaves [0, 1]: the loss clips, its gradient is ill-conditioned in float32 and float64 alike)
+        st['dropout'], ou['dropout'] = {}, {}
+        mask = g['set_mask'] & g['output_mask']
+        m = int(mask.sum())
+        targets = np.eye(2)[rng.integers(0, 2, m)].astype(np.float32)
+        weights = (rng.uniform(0.5, 1.5, m) / m).astype(np.float32)
+        s0 = (0.1 * rng.standard_normal((n, ds))).astype(np.float32) if d else None
+        ref = tro.train_step(g, st, ou, d, max_it, 0.0, s0, [{} for _ in range(max_it)], {}, targets, weights, loss='categorical_crossentropy', mean=False, graph_based=False)
+        graph = e.Graph(n, g['adjT'][0], g['adjT'][1], g['adjT'][2], g['arcT'][2], np.asarray(g['arcs'])[:, 2:][g['arcT'][1]], nodes, mask)
+        mst, mou = e.Mlp(st['weights'], st['activations'], bn), e.Mlp(ou['weights'], ou['activations'], False)
+        loop = e.Loop(graph, mst, mou, d, max_it, 0.0)
+        if d: loop.set_state0(s0)
+        kw = dict(dropout_state=[0.0] * (len(hidden) + 2), dropout_output=[0.0, 0.0],
+                  bn_state=np.concatenate(st['weights'][-4:-2]) if bn else None, bn_output=None)
+        res = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0, None, **kw)
+        tag = (case, d, nl, al, hidden, n, act, bn, max_it)
+        assert res['k'] == ref['k'], tag
+        assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss'])), tag
+        gscale = max(float(np.max(np.abs(w_))) for w_ in ref['grads_state'] + ref['grads_output'])
+        for got, want in list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output'])):
+            assert got.shape == want.shape and np.max(np.abs(got - want)) <= 1e-3 * max(float(np.max(np.abs(want))), 0.05 * gscale), \
+                (tag, got.shape, float(np.max(np.abs(got - want))), float(np.max(np.abs(want))))
+        res2 = loop.train_step(mst, mou, _by_source_csr(g, n), targets, weights, 0, None, **kw)
+        assert all(np.array_equal(a_, b_) for a_, b_ in zip(res['grads_state'] + res['grads_output'], res2['grads_state'] + res2['grads_output'])), tag
+        loop.close()
