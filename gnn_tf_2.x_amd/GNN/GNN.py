@@ -133,7 +133,9 @@ class GNNnodeBased(BaseClass):
             loop = _engine.Loop(dev_graph, self.net_state.device_mlp(self.device), self.net_output.device_mlp(self.device),
                                 self.state_vect_dim, self.max_iteration, self.state_threshold)
             cache[key] = (weakref.ref(self), loop)
-        loop.set_impl(self.impl)
+        if getattr(loop, '_impl_set', None) != self.impl:      # (gnn_loop_set_impl checks the fused path, which re-packs the weight images when the weights
+            loop.set_impl(self.impl)                          #  have changed - 0.17 ms after every optimizer step; the next inference Loop packs them anyway)
+            loop._impl_set = self.impl
         return loop
 
     def _run(self, dev_graph: _engine.Graph, training: bool, state0) -> tuple[float, _engine.Loop]:

@@ -292,7 +292,12 @@ class GraphTensor:
     def nodegraph_csr(self):
         """NodeGraph^T as CSR over graphs, ascending node inside a graph (input of gnn_loop_readout)."""
         ng = self.NodeGraph
+        cached = self.__dict__.get('_ng_csr')
+        if cached is not None and cached[0] is ng:          # (np.nonzero over the dense [N, G] matrix is 0.1 ms per call on a MUTAG batch: once per matrix)
+            return cached[1]
         cols, rows = np.nonzero(ng.T)
         indptr = np.zeros(ng.shape[1] + 1, dtype=np.int32)
         np.cumsum(np.bincount(cols, minlength=ng.shape[1]), out=indptr[1:])
-        return indptr, rows.astype(np.int32), ng[rows, cols].astype(np.float32)
+        csr = (indptr, rows.astype(np.int32), ng[rows, cols].astype(np.float32))
+        self.__dict__['_ng_csr'] = (ng, csr)
+        return csr
