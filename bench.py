@@ -258,11 +258,17 @@ def other_configs(engine, s, device=0):
         for lp, _, _ in loops:
             lp.run()
     dt_loop = time.perf_counter() - t1
+    t2 = time.perf_counter()                            # all ten batches in one call (gnn_loop_run_many: their launches side by side), then the readouts
+    for _ in range(reps):
+        engine.Loop.run_many([lp for lp, _, _ in loops])
+        for lp, ng, _ in loops: lp.readout(*ng)
+    dt_many = time.perf_counter() - t2
     out['mutag_batch32'] = {'loops_per_s': reps * len(loops) / dt, 'loop_only_per_s': reps * len(loops) / dt_loop,
+                            'side_by_side_loops_per_s': reps * len(loops) / dt_many,
                             'graphs_per_s': 32 * reps * len(loops) / dt, 'node_state_updates_per_s': updates / dt,
                             'mean_iterations': iters / (reps * len(loops)), 'us_per_iteration': 1e6 * dt / iters, 'persistent_one_launch_loop': bool(persistent),
                             'what': 'BASELINE configs[1] shape: 10 batches of 32 MUTAG graphs (~570 nodes each), net_state 31->32->32->14, max_iter 50, '
-                                    'threshold 0.01, GNN.Loop + NodeGraph readout per batch, host-timed (loop_only_per_s: without the readout)'}
+                                    'threshold 0.01, GNN.Loop + NodeGraph readout per batch, host-timed (loop_only_per_s: without the readout; side_by_side_loops_per_s: the ten batches through gnn_loop_run_many + readouts)'}
     for lp, _, _ in loops: lp.close()
     # ---- configs[4]: LGNN x 5 on the bench graph ----------------------------------------------------------------------------------
     layers, d, nl, al, t, max_it = 5, 64, 3, 1, 2, 30

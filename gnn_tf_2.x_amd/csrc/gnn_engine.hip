@@ -1894,6 +1894,51 @@ extern "C" int gnn_loop_run(gnn_loop *l, int training, float *k_out)
     return run_loops(&l, 1, k_out);
 }
 
+// Several INDEPENDENT loops (batches of a dataset: reference GNN_BaseClass.py:165-189 evaluates them one after the other) in one call.
+// Small graphs take the persistent one-launch path, and such a launch occupies a few dozen of the 256 CUs: all of them are queued, each on
+// its own loop's stream, before the first is waited for, so that they run side by side; the others run one after the other (each
+// fills the GPU by itself).  The results are those of n separate gnn_loop_run calls.
+extern "C" int gnn_loop_run_many(gnn_loop **loops, int n, float *k_out /* [n] */)
+{
+    ARGCHK(loops && n >= 1 && k_out, "bad arguments");
+    for (int i = 0; i < n; ++i) {
+        ARGCHK(loops[i], "loop %d is NULL", i);
+        ARGCHK(loops[i]->world == 1, "loop %d is one rank of a sharded job: gnn_loop_run / gnn_loop_run_group", i);
+        for (int j = 0; j < i; ++j) ARGCHK(loops[j] != loops[i], "loop %d is listed twice", i);
+    }
+    std::vector<char> queued((size_t)n, 0);
+    int rc = 0;
+    for (int i = 0; i < n; ++i) {
+        gnn_loop *l = loops[i];
+        bool fused = false;
+        if ((rc = loop_prepare(l, &fused))) return rc;
+        if (!(fused && gnn_small_supported(l))) continue;
+        bool output_done = false;
+        l->kfinal_host[1] = 0;
+        if ((rc = gnn_small_run(l, &output_done))) return rc;
+        if ((rc = loop_finish(l, false, output_done))) return rc;
+        queued[(size_t)i] = 1;
+    }
+    for (int i = 0; i < n; ++i)
+        if (!queued[(size_t)i] && (rc = run_loops(&loops[i], 1, &k_out[i]))) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (!queued[(size_t)i]) continue;
+        gnn_loop *l = loops[i];
+        HIPCHK(hipSetDevice(l->device));
+        HIPCHK(hipStreamSynchronize(l->stream));
+        if (l->kfinal_host[1] != 0) {          // a barrier spin gave up (too many launches side by side?): this one again, alone, one launch per body
+            l->ng_inlaunch = false;
+            l->small_disabled = true;
+            l->small_words_clean = false;
+            if ((rc = run_loops(&loops[i], 1, &k_out[i]))) return rc;
+            l->small_disabled = false;         // (alone it would have been resident: only this call falls back)
+            continue;
+        }
+        if ((rc = loop_collect(l, &k_out[i]))) return rc;
+    }
+    return GNN_OK;
+}
+
 extern "C" int gnn_loop_run_group(gnn_loop **loops, int n, float *k_out)
 {
     ARGCHK(loops && n >= 1, "bad arguments");

@@ -133,6 +133,10 @@ int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_output, int s
                     gnn_comm *comm /* NULL: single GPU */, gnn_loop **out);
 int gnn_loop_set_state0(gnn_loop *l, const float *state0, uint64_t seed);
 int gnn_loop_run(gnn_loop *l, int training, float *k_out);
+/* n independent loops (the batches of a dataset, which GNN_BaseClass.evaluate - reference GNN_BaseClass.py:165-189 - runs one after the
+ * other) in one call: the persistent launches of small graphs are all queued, each on its loop's stream, before the first is waited
+ * for, and run side by side on the GPU; larger graphs run one after the other.  k_out [n]; results as of n gnn_loop_run calls. */
+int gnn_loop_run_many(gnn_loop **loops, int n, float *k_out);
 int gnn_loop_get_state(const gnn_loop *l, float *state_out /* [n_rows, Ds] */);
 int gnn_loop_get_output(const gnn_loop *l, float *out /* [n_masked, T] */, int64_t *n_masked);
 /* GNNgraphBased.Loop readout (GNN/GNN.py:331-332, LGNN.py:278): out_graph = NodeGraph^T . out_nodes.

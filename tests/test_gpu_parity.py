@@ -716,6 +716,32 @@ def test_fused_kernel_random_shapes():
     assert ran >= 12
 
 
+def test_run_many_runs_small_loops_side_by_side():
+    """gnn_loop_run_many: the persistent launches of several small graphs queued on their own streams before any is waited for (they run
+    side by side), a graph too large for the persistent path in the same call; every loop's k, state and outputs bit-identical to the C
+    oracle, as if run alone - also on a second call, and with the graph readout folded into the launches."""
+    e = _engine()
+    rng = np.random.default_rng(77)
+    cases, loops, want = [], [], []
+    shapes = [(570, 0, 14, 3, (32, 32)), (300, 8, 3, 2, (16,)), (1999, 5, 2, 1, (7, 9)), (33, 16, 3, 1, (24,)), (4097, 8, 3, 2, (16,)),
+              (700, 24, 3, 2, (32, 20)), (9000, 8, 3, 2, (16,)), (640, 0, 5, 2, ())]
+    for n, d, nl, al, hidden in shapes:
+        g, st, ou, s0 = _case(rng, n=n, d=d, nl=nl, al=al, hidden=hidden, act='selu')
+        lp = e.Loop(_device_graph(g), e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), d, 20, 0.01)
+        lp.set_impl(1)
+        if d: lp.set_state0(s0)
+        loops.append(lp)
+        want.append(corc.loop_node(g, st, ou, d, 20, 0.01, s0))
+    assert sum(lp.set_persistent(True) for lp in loops) == len(shapes) - 1          # all but the 9,000-node graph
+    for _ in range(2):
+        ks = e.Loop.run_many(loops)
+        for lp, k, (kc, sc, oc) in zip(loops, ks, want):
+            assert k == kc and np.array_equal(lp.state(), sc) and np.array_equal(lp.output(), oc)
+    with pytest.raises((e.EngineError, ValueError)):
+        e.Loop.run_many([loops[0], loops[0]])
+    for lp in loops: lp.close()
+
+
 def test_lgnn_run_in_one_call_and_work_counters():
     """gnn_lgnn_run = LGNN.Loop (reference LGNN.py:263-290) of a whole stack through ONE C-ABI call: layer i on graphs[i], relabelling
     from the ORIGINAL graph in between; bit-identical to the C oracle chain.  gnn_counters_get: the algorithmic work of one iteration."""
