@@ -643,6 +643,44 @@ __global__ void __launch_bounds__(256) k_dense_fwd(int64_t n, int n_in, int n_in
     });
 }
 
+// ALL Dense layers of a Sequential on a row tile in one launch (few rows: a MUTAG-sized step is bound by the number of launches): the
+// tile's activations go from layer to layer through LDS, every layer's output is also written out (the backward pass reads it); the
+// arithmetic per layer is that of k_dense_fwd (same dense_rows chains: identical bits).  No Dropout between the layers, softmax only as
+// the last activation (applied by the caller).  LDS: 2 R maxpad + 256 R floats.
+struct MlpFwd {
+    int64_t n;
+    int L, maxpad;
+    int dims[GNN_FUSED_MAXL + 2], pad[GNN_FUSED_MAXL + 2], cshift[GNN_FUSED_MAXL + 1], act[GNN_FUSED_MAXL + 1];
+    const float *W[GNN_FUSED_MAXL + 1], *b[GNN_FUSED_MAXL + 1];
+    const float *X;
+    float *Y[GNN_FUSED_MAXL + 1];
+};
+template <int R>
+__global__ void __launch_bounds__(256) k_mlp_fwd(const MlpFwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *in = lds, *out = lds + (size_t)R * p.maxpad, *ps = lds + (size_t)2 * R * p.maxpad;
+    const int64_t i0 = (int64_t)blockIdx.x * R;
+    for (int t = threadIdx.x; t < R * p.pad[0]; t += blockDim.x) {
+        const int r = t / p.pad[0], k = t - r * p.pad[0];
+        in[t] = (k < p.dims[0] && i0 + r < p.n) ? p.X[(i0 + r) * p.dims[0] + k] : 0.0f;
+    }
+    for (int l = 0; l < p.L; ++l) {
+        const int no = p.dims[l + 1], npad = p.pad[l + 1], act = p.act[l];
+        for (int t = threadIdx.x; t < R * npad; t += blockDim.x) out[t] = 0.0f;          // (the padding columns of the next input)
+        __syncthreads();
+        const float *bl = p.b[l];
+        float *Yl = p.Y[l];
+        dense_rows<R>(p.dims[l], p.pad[l], no, p.cshift[l], p.W[l], in, ps, [&](int r, int j, float v) {
+            v = v + bl[j];
+            if (act != GNN_ACT_SOFTMAX) v = gnn_act(v, act);
+            out[r * npad + j] = v;
+            if (i0 + r < p.n) Yl[(i0 + r) * no + j] = v;
+        });
+        float *t_ = in; in = out; out = t_;          // (dense_rows ends with a barrier)
+    }
+}
+
 // One Dense layer of the backward pass in one launch: the blocks of the weight / bias gradient (first wg_blocks ids: the heavier
 // ones) and the blocks of d h_in run side by side; both read d z, neither reads the other's result.
 struct LayerBwd {
@@ -1836,6 +1874,40 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
             mask_off += (size_t)n * width;
         }
         if (l == L) break;
+        // few rows, no Dropout between the layers: every Dense layer of the net in one launch (k_mlp_fwd)
+        if (l == 0 && L >= 2 && L <= GNN_FUSED_MAXL + 1 && n > 0 && !tg_many_rows(n)) {
+            bool ok = true;
+            int maxpad = (m->dims[0] + 3) & ~3;
+            for (int q = 1; q <= L; ++q) {
+                if (q < L && (net.rate[q] != 0.0f || m->acts[q - 1] == GNN_ACT_SOFTMAX)) ok = false;
+                maxpad = std::max(maxpad, (m->dims[q] + 3) & ~3);
+            }
+            constexpr int R = 8;
+            const size_t lds = sizeof(float) * ((size_t)2 * R * maxpad + (size_t)256 * R);
+#ifdef GNN_DIAG
+            static const bool off = getenv("GNN_TRAIN_MLP_FUSED") && atoi(getenv("GNN_TRAIN_MLP_FUSED")) == 0;
+            if (off) ok = false;
+#endif
+            if (ok && lds <= 64 * 1024) {
+                MlpFwd p{};
+                p.n = n; p.L = L; p.maxpad = maxpad; p.X = h;
+                for (int q = 0; q <= L; ++q) { p.dims[q] = m->dims[q]; p.pad[q] = (m->dims[q] + 3) & ~3; }
+                for (int q = 0; q < L; ++q) {
+                    if ((rc = buf.get(&c.a[q], (size_t)n * m->dims[q + 1]))) return rc;
+                    p.cshift[q] = dense_cshift(m->dims[q + 1]); p.act[q] = m->acts[q]; p.W[q] = m->W[q]; p.b[q] = m->b[q]; p.Y[q] = c.a[q];
+                    c.hin[q] = q == 0 ? h : c.a[q - 1];
+                }
+                hipLaunchKernelGGL((k_mlp_fwd<R>), cdiv(n, R), 256, lds, st, p);
+                HIPCHK(hipGetLastError());
+                if (m->acts[L - 1] == GNN_ACT_SOFTMAX) {
+                    hipLaunchKernelGGL(k_act_fwd, cdiv(n, 256), 256, 0, st, n, m->dims[L], c.a[L - 1], m->acts[L - 1], c.a[L - 1]);
+                    HIPCHK(hipGetLastError());
+                }
+                h = c.a[L - 1];
+                l = L - 1;               // (the loop goes on with index L: the Dropout in front of BatchNormalization, if any)
+                continue;
+            }
+        }
         const int no = m->dims[l + 1];
         c.hin[l] = h;
         if ((rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
