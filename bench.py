@@ -330,10 +330,13 @@ def main():
     ap.add_argument('--impl', type=int, default=2, help='2: fused kernel, split bf16 MFMA (default, what the engine runs by default); '
                                                        '1: fused kernel, bit-exact f32 MFMA; 0: one kernel per TF op')
     ap.add_argument('--act', default='selu', help='net_state activation (experiments; the BASELINE config is selu)')
-    ap.add_argument('--exchange', choices=['auto', 'full', 'halo', 'slice'], default='auto',
+    ap.add_argument('--exchange', choices=['auto', 'full', 'halo', 'slice', 'slice1'], default='auto',
                     help='N > 1: all-gather of whole shards, of boundary rows only (gnn_graph_create_halo), or the feature-sliced '
                          'all-to-all (gnn_loop_set_slice_exchange: every rank aggregates its columns for all nodes).  auto: slice '
-                         'from 4 ranks on (2 (P-1)/P^2 instead of (P-1)/P of the state received per iteration), full below')
+                         'from 4 ranks on (2 (P-1)/P^2 instead of (P-1)/P of the state received per iteration), full below.  slice: the '
+                         'return all-to-all as ONE grouped call behind the aggregation; slice1: block by block on a second stream beside it '
+                         '(gnn_loop_set_slice_exchange(l, 1): verified in loopback groups and over the tests\' stand-in transport, never on '
+                         'RCCL with more than one rank - until it has been, the bench keeps to the one-shot form)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the untimed configs[1] / configs[4] figures under config.other_configs')
     ap.add_argument('--cpu-iters', type=int, default=20)
@@ -384,9 +387,9 @@ def main():
     loop = engine.Loop(graph, mst, mou, d, args.max_iter, 0.0, comm)
     impl_used = loop.set_impl(args.impl)
     loop.set_state0(state0[rb:rb + nr])
-    if world > 1 and args.exchange == 'slice':
+    if world > 1 and args.exchange in ('slice', 'slice1'):
         graph.set_full_adjacency(n, s['indptr'], s['adj_src'], s['adj_w'])
-        loop.set_slice_exchange(True)
+        loop.set_slice_exchange(1 if args.exchange == 'slice1' else 2)
 
     def barrier(value=0.0):
         engine._check(engine.lib().gnn_device_synchronize(local_rank))
@@ -474,7 +477,7 @@ def main():
                                    f'max_iter={args.max_iter}, threshold=0 (all iterations run); the loop-invariant label aggregates '
                                    f'(GNN.py:259, :263; 0.2 ms) are kept between Loops until the labels change, see cold_aggregates_ms_per_step',
                        'iterations_per_step': k_total / args.steps,
-                       'parallelism': (f'node-range shards x{world}, ' + ('RCCL all-to-all of column slices (feature-sliced aggregation)' if args.exchange == 'slice' else 'RCCL all-gather of ' + ('boundary' if args.exchange == 'halo' else 'owned') + ' state rows') + ' per iteration') if world > 1 else 'single GPU',
+                       'parallelism': (f'node-range shards x{world}, ' + ('RCCL all-to-all of column slices (feature-sliced aggregation' + (', return all-to-all block by block beside the aggregation)' if args.exchange == 'slice1' else ')') if args.exchange in ('slice', 'slice1') else 'RCCL all-gather of ' + ('boundary' if args.exchange == 'halo' else 'owned') + ' state rows') + ' per iteration') if world > 1 else 'single GPU',
                        'impl': {2: 'fused gather+MLP kernel, dense layers on the bf16 MFMA with fp32 operands cut into 3 exact bf16 '
                                    'pieces (6 piece products, fp32 accumulate; error per product <= 3*2^-24)',
                                 1: 'fused gather+MLP kernel, dense layers on the f32 MFMA (bit-identical to the oracle)',

@@ -120,7 +120,7 @@ def test_ranks_as_processes_match_oracle(world):
                 assert got[0].shape == want.shape and np.max(np.abs(got[0] - want)) < tol, (tag, name, i, float(np.max(np.abs(got[0] - want))), tol)
 
 
-@pytest.mark.parametrize('gpus,exchange', [(2, 'auto'), (4, 'auto'), (3, 'halo')])
+@pytest.mark.parametrize('gpus,exchange', [(2, 'auto'), (4, 'auto'), (4, 'slice1'), (3, 'halo')])
 def test_bench_launcher_runs_all_ranks_end_to_end(gpus, exchange):
     """`python bench.py --gpus N` bare: the launcher starts N rank processes, they rendezvous, shard the graph, run the timed Loops through
     the communicator and rank 0 prints the JSON line (a reduced graph; all ranks on device 0 over the stand-in transport)."""
