@@ -138,8 +138,26 @@ class GNNnodeBased(BaseClass):
             loop._impl_set = self.impl
         return loop
 
+    def _prerun(self, graphs) -> list:
+        """evaluate() over several graphs (reference GNN_BaseClass.py:165-189 walks them one after the other): their device Loops in ONE
+        gnn_loop_run_many call - the persistent launches of small graphs run side by side - and the Loop() calls that follow take these
+        results instead of running again.  Returns the loops it marked (evaluate clears the marks when it is done)."""
+        if len(graphs) < 2 or not all(isinstance(g, GraphTensor) for g in graphs):
+            return []
+        loops = [self._device_loop(g.device_graph(self.device)) for g in graphs]
+        if len({id(lp) for lp in loops}) != len(loops):
+            return []                                       # the same graph twice in the list: one after the other, as before
+        if self.state_vect_dim > 0:
+            for lp in loops: lp.set_state0(None, self.seed)
+        for lp, k in zip(loops, _engine.Loop.run_many(loops)):
+            lp._fresh = k
+        return loops
+
     def _run(self, dev_graph: _engine.Graph, training: bool, state0) -> tuple[float, _engine.Loop]:
         loop = self._device_loop(dev_graph)
+        if not training and state0 is None and getattr(loop, '_fresh', None) is not None:
+            k, loop._fresh = loop._fresh, None              # run by _prerun a moment ago, with these weights and this initial state
+            return k, loop
         if self.state_vect_dim > 0:
             loop.set_state0(state0, self.seed)
         if training:
@@ -237,6 +255,9 @@ class GNNedgeBased(GNNnodeBased):
     """GNN for edge-based problems: node-based state loop, then net_output on [state(i0) | state(i1) | arc label] of the
     arcs selected by set_mask & output_mask (reference GNN.py:286-302; the pairing of index pairs and arc labels by position
     is the reference's)."""
+
+    def _prerun(self, graphs) -> list:
+        return []                                           # (the per-arc readout is configured inside Loop: one graph after the other)
 
     def Loop(self, g: Union[GraphObject, GraphTensor], *, training: bool = False, state0=None, _want_state: bool = True):
         if isinstance(g, GraphObject): g = GraphTensor.fromGraphObject(g)

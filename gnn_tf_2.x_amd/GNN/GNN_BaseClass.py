@@ -80,7 +80,11 @@ class BaseClass(ABC):
     def evaluate(self, g) -> tuple:
         """metrics dict (+ 'It', 'Loss'), y_true, y_pred, targets, y_score over one graph or a list of graphs."""
         graphs = self.checktype(g)
-        iters, losses, targets, outs = zip(*[self.evaluate_single_graph(i, training=False) for i in graphs])
+        marked = self._prerun(graphs) if hasattr(self, '_prerun') else []       # (GNN node- / graph-based: the graphs' Loops in one call, small ones side by side)
+        try:
+            iters, losses, targets, outs = zip(*[self.evaluate_single_graph(i, training=False) for i in graphs])
+        finally:
+            for lp in marked: lp._fresh = None
         targets = np.concatenate(targets, axis=0)
         y_score = np.concatenate(outs, axis=0)
         classify = self.addressed_problem == 'c'

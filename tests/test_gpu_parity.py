@@ -795,3 +795,31 @@ def test_communicator_may_be_destroyed_before_its_loops():
     kc, sc, oc = corc.loop_node(g, st, ou, 8, 10, 0.01, s0)
     assert k == kc and np.array_equal(loop.state(), sc)
     loop.close()
+
+
+@pytest.mark.parametrize('graph_based,d', [(True, 0), (False, 6)])
+def test_evaluate_runs_the_graphs_side_by_side_with_the_same_results(graph_based, d):
+    """GNN_BaseClass.evaluate over a list of GraphTensors sends their Loops through gnn_loop_run_many; metrics, iteration counts and every
+    output are those of evaluating the graphs one by one (reference GNN_BaseClass.py:165-189)."""
+    import sys, os
+    from GNN.graph_class import GraphObject, GraphTensor
+    from GNN.GNN import GNNgraphBased, GNNnodeBased
+    from GNN.MLP import MLP, get_inout_dims
+    from GNN import optimizers, losses, GNN_utils as utils
+    rng = np.random.default_rng(5 + d)
+    graphs = [utils.randomGraph(int(rng.integers(15, 40)), 3, 1, 2, 0.3, problem_based='g' if graph_based else 'n') for _ in range(24)]
+    batches = [GraphTensor.fromGraphObject(GraphObject.merge(graphs[i:i + 6], problem_based='g' if graph_based else 'n', aggregation_mode='average')) for i in range(0, 24, 6)]
+    pb = 'g' if graph_based else 'n'
+    ins, ls = get_inout_dims('state', 3, 1, 2, pb, d, [12])
+    ino, lo = get_inout_dims('output', 3, 1, 2, pb, d, [])
+    cls = GNNgraphBased if graph_based else GNNnodeBased
+    gnn = cls(MLP(input_dim=ins, layers=ls, activations=['tanh'] * len(ls), kernel_initializer='lecun_normal', bias_initializer='lecun_normal'),
+              MLP(input_dim=ino, layers=lo, activations=['softmax'], kernel_initializer='glorot_normal', bias_initializer='glorot_normal', batch_normalization=False),
+              optimizers.Adam(1e-3), losses.categorical_crossentropy, {}, d, 12, 0.01, 'c', path_writer='/tmp/gnn_test_eval/', namespace='t')
+    gnn.seed = 11
+    one_by_one = [gnn.evaluate_single_graph(b, training=False) for b in batches]
+    metrics, y_true, y_pred, targets, y_score = gnn.evaluate(batches)
+    assert np.array_equal(y_score, np.concatenate([o[3] for o in one_by_one]))
+    assert metrics['It'] == int(np.mean(np.asarray([o[0] for o in one_by_one], np.float32)))
+    assert abs(metrics['Loss'] - float(np.mean(np.asarray([o[1] for o in one_by_one], np.float32)))) < 1e-6
+    assert all(getattr(lp, '_fresh', None) is None for b in batches for (_, lp) in b.device_graph(gnn.device).__dict__.get('_loops', {}).values())
