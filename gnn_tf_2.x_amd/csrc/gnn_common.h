@@ -266,6 +266,7 @@ struct gnn_loop {
     float *agg_own = nullptr;               // [shard_rows, Ds]: aggregated states of the owned rows (GNN.py:234), input of the body
     void *train_ctx = nullptr;              // gnn_train.hip: what train_forward leaves for train_backward
     void *train_arena = nullptr;            // gnn_train.hip: device scratch slabs kept from step to step
+    int train_k_hint = 0;                   // bodies the last training forward of this loop ran (the next one enqueues that many + 1 before it looks at the gates)
 };
 
 // gnn_engine.hip

@@ -2505,7 +2505,14 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     int *flags_all = nullptr;
     if (sharded && (rc = buf.get(&flags_all, flag_words * (size_t)l->world))) return rc;
     while (k < 0) {
-        const int target = std::min(max_iter, enq + TRAIN_CHUNK);
+        // the first look at the gates comes behind as many bodies as the loop's last training forward ran, plus one (a batch's iteration
+        // count moves slowly from epoch to epoch: k = 11 is then one synchronisation and one dropped body instead of three and four)
+        int chunk = enq == 0 && l->train_k_hint >= TRAIN_CHUNK ? l->train_k_hint + 1 : TRAIN_CHUNK;
+#ifdef GNN_DIAG
+        static const bool hint_off = getenv("GNN_TRAIN_K_HINT") && atoi(getenv("GNN_TRAIN_K_HINT")) == 0;
+        if (hint_off) chunk = TRAIN_CHUNK;
+#endif
+        const int target = std::min(max_iter, enq + chunk);
         for (; enq < target; ++enq) {
             float *inp = nullptr, *y = nullptr;
             uint8_t *keep0 = nullptr;
@@ -2573,6 +2580,7 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
     if ((rc = net_forward(st, buf, no_, M, feats, nullptr, d_masks_o, seed + 104729ull, cx->co, &cx->out_nodes, comm))) return rc;
     cx->state = state;
     cx->k = k;
+    l->train_k_hint = k;
     // publish the training-mode state / outputs as the loop's result: gnn_loop_get_state / get_output / readout and
     // gnn_graph_update_labels (LGNN stacking) read them exactly like an inference run's
     if (sharded) {                                     // the whole replica, as after an inference Loop (k == 0 with D == 0: the label rows there are)
