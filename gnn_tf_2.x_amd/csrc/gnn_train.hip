@@ -654,6 +654,16 @@ struct MlpFwd {
     const float *W[GNN_FUSED_MAXL + 1], *b[GNN_FUSED_MAXL + 1];
     const float *X;
     float *Y[GNN_FUSED_MAXL + 1];
+    // build != 0 (net_state of a loop body, no Dropout in front of the first layer): the input rows are not read from X but BUILT here -
+    // the concat of k_train_input (GNN.py:223-239: own state | template columns | aggregated neighbour states, the fmaf chain over the
+    // arcs in stored order) - written to X_out for the backward pass, and the body's gate (GNN.py:202-220) is evaluated per row
+    int build, Ds, c_aggs;
+    const float *tmpl, *state, *own, *own_prev;
+    const int32_t *indptr, *adj_src;
+    const float *adj_w;
+    float *X_out;
+    float thr;
+    int *flag;
 };
 template <int R>
 __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpFwd p)
@@ -661,9 +671,51 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const MlpFwd p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *in = lds, *out = lds + (size_t)R * p.maxpad, *ps = lds + (size_t)2 * R * p.maxpad;
     const int64_t i0 = (int64_t)blockIdx.x * R;
-    for (int t = threadIdx.x; t < R * p.pad[0]; t += blockDim.x) {
-        const int r = t / p.pad[0], k = t - r * p.pad[0];
-        in[t] = (k < p.dims[0] && i0 + r < p.n) ? p.X[(i0 + r) * p.dims[0] + k] : 0.0f;
+    if (p.build) {
+        const int in_s = p.dims[0], Ds = p.Ds, c_aggs = p.c_aggs;
+        int moved = 0;
+        for (int t = threadIdx.x; t < R * p.pad[0]; t += blockDim.x) {
+            const int r = t / p.pad[0], c = t - r * p.pad[0];
+            const int64_t row = i0 + r;
+            float v = 0.0f;
+            if (c < in_s && row < p.n) {
+                if (c < Ds) v = p.own[row * Ds + c];
+                else if (c >= c_aggs && c < c_aggs + Ds) {
+                    const int cc = c - c_aggs;
+                    const int32_t e1 = p.indptr[row + 1];
+                    for (int32_t e = p.indptr[row]; e < e1; e += 4) {          // four arcs per step: their loads are in flight together
+                        float w[4], x[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool in_ = e + u < e1;
+                            w[u] = in_ ? p.adj_w[e + u] : 0.0f;
+                            x[u] = in_ ? p.state[(int64_t)p.adj_src[e + u] * Ds + cc] : 0.0f;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (e + u < e1) v = __builtin_fmaf(w[u], x[u], v);
+                    }
+                } else
+                    v = p.tmpl[row * in_s + c];
+                p.X_out[row * in_s + c] = v;
+                if (c == 0) {                              // the while-condition of this body for the row (k_train_input's chain)
+                    float dist = 0.0f, nrm = 0.0f;
+                    for (int q = 0; q < Ds; ++q) {
+                        const float o = p.own_prev ? p.own_prev[row * Ds + q] : 1.0f;
+                        const float df = p.own[row * Ds + q] - o;
+                        dist = dist + df * df;
+                        nrm = nrm + o * o;
+                    }
+                    moved |= sqrtf(dist) > p.thr * sqrtf(nrm) ? 1 : 0;
+                }
+            }
+            in[t] = v;
+        }
+        if (__any(moved) && (threadIdx.x & 63) == 0) gnn_flag_raise(p.flag);
+    } else {
+        for (int t = threadIdx.x; t < R * p.pad[0]; t += blockDim.x) {
+            const int r = t / p.pad[0], k = t - r * p.pad[0];
+            in[t] = (k < p.dims[0] && i0 + r < p.n) ? p.X[(i0 + r) * p.dims[0] + k] : 0.0f;
+        }
     }
     for (int l = 0; l < p.L; ++l) {
         const int no = p.dims[l + 1], npad = p.pad[l + 1], act = p.act[l];
@@ -1830,9 +1882,33 @@ int net_setup(hipStream_t st, Buf &buf, Net &net, const gnn_mlp *m, const float 
 
 // training-mode forward of one Sequential on n rows (x: [n, dims[0]]); *y_out: [n, dims.back()].  keep0 != NULL: the Dropout
 // in front of the first Dense layer has been applied by the producer of x (k_train_input), its mask is keep0.
+// few rows, no Dropout between the layers, softmax at most as the last activation: all Dense layers in one launch (k_mlp_fwd)?
+static bool mlp_small_fused_ok(const Net &net, int64_t n, size_t *lds_out = nullptr, int *maxpad_out = nullptr)
+{
+    const gnn_mlp *m = net.m;
+    const int L = m->n_layers;
+    if (!(L >= 2 && L <= GNN_FUSED_MAXL + 1 && n > 0 && !tg_many_rows(n))) return false;
+    int maxpad = (m->dims[0] + 3) & ~3;
+    for (int q = 1; q <= L; ++q) {
+        if (q < L && (net.rate[q] != 0.0f || m->acts[q - 1] == GNN_ACT_SOFTMAX)) return false;
+        maxpad = std::max(maxpad, (m->dims[q] + 3) & ~3);
+    }
+    const size_t lds = sizeof(float) * ((size_t)2 * 8 * maxpad + (size_t)256 * 8);
+#ifdef GNN_DIAG
+    static const bool off = getenv("GNN_TRAIN_MLP_FUSED") && atoi(getenv("GNN_TRAIN_MLP_FUSED")) == 0;
+    if (off) return false;
+#endif
+    if (lds > 64 * 1024) return false;
+    if (lds_out) *lds_out = lds;
+    if (maxpad_out) *maxpad_out = maxpad;
+    return true;
+}
+
 // comm != NULL (sharded forward, one process per rank): the BatchNormalization statistics are those of the rows of ALL ranks.
+// build != NULL (only where mlp_small_fused_ok and no Dropout in front of the first layer): x has NOT been filled - k_mlp_fwd builds the
+// concat rows itself (and writes them to x for the backward pass); the build fields of *build say from what.
 int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t *keep0, const uint8_t *masks, uint64_t seed, NetCache &c,
-                float **y_out, gnn_comm *comm = nullptr)
+                float **y_out, gnn_comm *comm = nullptr, const MlpFwd *build = nullptr)
 {
     const gnn_mlp *m = net.m;
     const int L = m->n_layers;
@@ -1875,39 +1951,30 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
         }
         if (l == L) break;
         // few rows, no Dropout between the layers: every Dense layer of the net in one launch (k_mlp_fwd)
-        if (l == 0 && L >= 2 && L <= GNN_FUSED_MAXL + 1 && n > 0 && !tg_many_rows(n)) {
-            bool ok = true;
-            int maxpad = (m->dims[0] + 3) & ~3;
-            for (int q = 1; q <= L; ++q) {
-                if (q < L && (net.rate[q] != 0.0f || m->acts[q - 1] == GNN_ACT_SOFTMAX)) ok = false;
-                maxpad = std::max(maxpad, (m->dims[q] + 3) & ~3);
-            }
+        size_t lds_small = 0;
+        int maxpad = 0;
+        if (l == 0 && mlp_small_fused_ok(net, n, &lds_small, &maxpad)) {
             constexpr int R = 8;
-            const size_t lds = sizeof(float) * ((size_t)2 * R * maxpad + (size_t)256 * R);
-#ifdef GNN_DIAG
-            static const bool off = getenv("GNN_TRAIN_MLP_FUSED") && atoi(getenv("GNN_TRAIN_MLP_FUSED")) == 0;
-            if (off) ok = false;
-#endif
-            if (ok && lds <= 64 * 1024) {
-                MlpFwd p{};
-                p.n = n; p.L = L; p.maxpad = maxpad; p.X = h;
-                for (int q = 0; q <= L; ++q) { p.dims[q] = m->dims[q]; p.pad[q] = (m->dims[q] + 3) & ~3; }
-                for (int q = 0; q < L; ++q) {
-                    if ((rc = buf.get(&c.a[q], (size_t)n * m->dims[q + 1]))) return rc;
-                    p.cshift[q] = dense_cshift(m->dims[q + 1]); p.act[q] = m->acts[q]; p.W[q] = m->W[q]; p.b[q] = m->b[q]; p.Y[q] = c.a[q];
-                    c.hin[q] = q == 0 ? h : c.a[q - 1];
-                }
-                hipLaunchKernelGGL((k_mlp_fwd<R>), cdiv(n, R), 256, lds, st, p);
-                HIPCHK(hipGetLastError());
-                if (m->acts[L - 1] == GNN_ACT_SOFTMAX) {
-                    hipLaunchKernelGGL(k_act_fwd, cdiv(n, 256), 256, 0, st, n, m->dims[L], c.a[L - 1], m->acts[L - 1], c.a[L - 1]);
-                    HIPCHK(hipGetLastError());
-                }
-                h = c.a[L - 1];
-                l = L - 1;               // (the loop goes on with index L: the Dropout in front of BatchNormalization, if any)
-                continue;
+            MlpFwd p{};
+            if (build) { p = *build; p.build = 1; p.X_out = h; }
+            p.n = n; p.L = L; p.maxpad = maxpad; p.X = h;
+            for (int q = 0; q <= L; ++q) { p.dims[q] = m->dims[q]; p.pad[q] = (m->dims[q] + 3) & ~3; }
+            for (int q = 0; q < L; ++q) {
+                if ((rc = buf.get(&c.a[q], (size_t)n * m->dims[q + 1]))) return rc;
+                p.cshift[q] = dense_cshift(m->dims[q + 1]); p.act[q] = m->acts[q]; p.W[q] = m->W[q]; p.b[q] = m->b[q]; p.Y[q] = c.a[q];
+                c.hin[q] = q == 0 ? h : c.a[q - 1];
             }
+            hipLaunchKernelGGL((k_mlp_fwd<R>), cdiv(n, R), 256, lds_small, st, p);
+            HIPCHK(hipGetLastError());
+            if (m->acts[L - 1] == GNN_ACT_SOFTMAX) {
+                hipLaunchKernelGGL(k_act_fwd, cdiv(n, 256), 256, 0, st, n, m->dims[L], c.a[L - 1], m->acts[L - 1], c.a[L - 1]);
+                HIPCHK(hipGetLastError());
+            }
+            h = c.a[L - 1];
+            l = L - 1;               // (the loop goes on with index L: the Dropout in front of BatchNormalization, if any)
+            continue;
         }
+        if (build) return gnn_fail(GNN_ERR_STATE, "internal: the input rows were left to a fused forward that did not run");
         const int no = m->dims[l + 1];
         c.hin[l] = h;
         if ((rc = buf.get(&c.a[l], (size_t)n * no))) return rc;
@@ -2522,7 +2589,14 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
             const uint8_t *mk = d_masks_s ? d_masks_s + mask_iter_bytes * (size_t)enq : nullptr;
             const uint64_t sd = seed + 7919ull * (uint64_t)(enq + 1);
             const float *own_cur = states[enq] + own_off * Ds, *own_prev = enq ? states[enq - 1] + own_off * Ds : (const float *)nullptr;
-            if (N == 0) {
+            MlpFwd build{};
+            const bool fused_input = N > 0 && r0 == 0.0f && mlp_small_fused_ok(ns, N);
+            if (fused_input) {
+                // few rows: k_mlp_fwd builds the concat rows itself (one launch for input + all Dense layers) and evaluates the gate
+                build.Ds = Ds; build.c_aggs = c_aggs; build.tmpl = tmpl; build.state = states[enq]; build.own = own_cur; build.own_prev = own_prev;
+                build.indptr = g->sh->indptr; build.adj_src = g->sh->adj_src; build.adj_w = g->sh->adj_w; build.thr = l->thr;
+                build.flag = flags + (size_t)enq * GNN_FLAG_WORDS;
+            } else if (N == 0) {
                 // (a rank without rows: nothing to compute, it only takes part in the exchanges below)
             } else if (r0 == 0.0f && (Ds & 3) == 0 && Ds <= 64 && tg_many_rows(N)) {
                 // many rows: the concat 16 lanes per row, gate i = condition(state_i, state_{i-1}) by k_check beside it
@@ -2538,7 +2612,7 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
                 HIPCHK(hipGetLastError());
             }
             cx->caches.emplace_back();
-            if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y, comm))) return rc;
+            if ((rc = net_forward(st, buf, ns, N, inp, keep0, mk, sd, cx->caches.back(), &y, comm, fused_input ? &build : nullptr))) return rc;
             if (sharded) {                             // the new rows of all ranks: what the next body gathers from
                 float *rep = nullptr;
                 if ((rc = replicate(y, &rep))) return rc;
