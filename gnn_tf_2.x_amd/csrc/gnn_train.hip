@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(int64_t n, int F, int cw_shift
 // does) in ONE single-block launch instead of k_bn_stats + k_bn_apply: per column the rows are taken by 1024 / CW lanes in a fixed
 // interleave and the lane results merged in lane order (mean first, then the squared deviations: two passes like k_bn_stats), then the
 // same normalisation as k_bn_apply.  Dynamic LDS: 2 F floats.
-constexpr int64_t GNN_BN_SMALL = 32768;
+constexpr int64_t GNN_BN_SMALL = 12288;         // elements: the backward kernel keeps two copies in LDS (96 KB)
 inline bool bn_small(int64_t n, int F)
 {
 #ifdef GNN_DIAG
@@ -346,23 +346,39 @@ __device__ __forceinline__ float bn_small_colsum(float v, float *red, int CW, in
     }
     return red[c];
 }
+// all n * F values of the block's matrix from memory into LDS with every load in flight at once (a single block that walks its rows with a
+// load per step is a chain of L2 latencies: 13 - 20 us per launch for a MUTAG batch, measured; staged: a few)
+__device__ __forceinline__ void bn_small_stage(const float *__restrict__ src, float *dst, int total)
+{
+    for (int i0 = 0; i0 < total; i0 += 8 * 1024) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + (int)threadIdx.x; t[u] = i < total ? src[i] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + (int)threadIdx.x; if (i < total) dst[i] = t[u]; }
+    }
+}
+// dynamic LDS: 2 F + n F floats
 __global__ void __launch_bounds__(1024) k_bn_small_fwd(int64_t n, int F, int cw_shift, const float *__restrict__ h, float eps, const float *gamma, const float *beta,
                                                        float *xhat, float *y, float *stats)
 {
     extern __shared__ float bsh[];
     __shared__ float red[1024];
-    float *sm = bsh, *sinv = bsh + F;
+    float *sm = bsh, *sinv = bsh + F, *hv = bsh + 2 * F;
+    const int total = (int)(n * F);
+    bn_small_stage(h, hv, total);
     const int CW = 1 << cw_shift, ZL = 1024 >> cw_shift;
     const int c = threadIdx.x & (CW - 1), zl = threadIdx.x >> cw_shift;
     for (int jb = 0; jb < F; jb += CW) {
         const int j = jb + c;
         float a0 = 0.0f;
+        __syncthreads();
         if (j < F)
-            for (int64_t r = zl; r < n; r += ZL) a0 += h[r * F + j];
+            for (int r = zl; r < (int)n; r += ZL) a0 += hv[r * F + j];
         const float m = bn_small_colsum(a0, red, CW, ZL, c, zl) / (float)n;
         a0 = 0.0f;
         if (j < F)
-            for (int64_t r = zl; r < n; r += ZL) { const float dv = h[r * F + j] - m; a0 += dv * dv; }
+            for (int r = zl; r < (int)n; r += ZL) { const float dv = hv[r * F + j] - m; a0 += dv * dv; }
         const float var = bn_small_colsum(a0, red, CW, ZL, c, zl) / (float)n;
         if (zl == 0 && j < F) {
             sm[j] = m;
@@ -371,10 +387,9 @@ __global__ void __launch_bounds__(1024) k_bn_small_fwd(int64_t n, int F, int cw_
         }
     }
     __syncthreads();
-    const int total = (int)(n * F);
     for (int i = threadIdx.x; i < total; i += 1024) {
         const int j = i % F;
-        const float xh = (h[i] - sm[j]) * sinv[j];
+        const float xh = (hv[i] - sm[j]) * sinv[j];
         xhat[i] = xh;
         y[i] = gamma[j] * xh + beta[j];
     }
@@ -463,20 +478,25 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_s
 // The backward pass of BatchNormalization for a small batch in one single-block launch (k_colreduce2 + k_bn_bwd_apply otherwise): the two
 // sums per column (they are also the gamma / beta gradients: written to chunk 0 of the partials, the other chunks' slots zeroed), then
 // d x and, fused, the derivative of the layer's activation.  Dynamic LDS: 2 F floats.
+// dynamic LDS: 2 F + 2 n F floats (d and xhat staged: bn_small_stage)
 __global__ void __launch_bounds__(1024) k_bn_small_bwd(int64_t n, int F, int cw_shift, float *d, const float *__restrict__ xhat, const float *gamma,
                                                        const float *stats, float eps, float *p_dyx, float *p_dy, int64_t pstride, int parts,
                                                        const float *__restrict__ a, int act)
 {
     extern __shared__ float bsh[];
     __shared__ float red[1024];
-    float *s_dyx = bsh, *s_dy = bsh + F;
+    const int total = (int)(n * F);
+    float *s_dyx = bsh, *s_dy = bsh + F, *dv = bsh + 2 * F, *xv = dv + total;
+    bn_small_stage(d, dv, total);
+    bn_small_stage(xhat, xv, total);
     const int CW = 1 << cw_shift, ZL = 1024 >> cw_shift;
     const int c = threadIdx.x & (CW - 1), zl = threadIdx.x >> cw_shift;
     for (int jb = 0; jb < F; jb += CW) {
         const int j = jb + c;
         float a0 = 0.0f, a1 = 0.0f;
+        __syncthreads();
         if (j < F)
-            for (int64_t r = zl; r < n; r += ZL) { const float v = d[r * F + j]; a0 += v * xhat[r * F + j]; a1 += v; }
+            for (int r = zl; r < (int)n; r += ZL) { const float v = dv[r * F + j]; a0 += v * xv[r * F + j]; a1 += v; }
         a0 = bn_small_colsum(a0, red, CW, ZL, c, zl);
         a1 = bn_small_colsum(a1, red, CW, ZL, c, zl);
         if (zl == 0 && j < F) {
@@ -486,12 +506,11 @@ __global__ void __launch_bounds__(1024) k_bn_small_bwd(int64_t n, int F, int cw_
         }
     }
     __syncthreads();
-    const int total = (int)(n * F);
     const float m = (float)n;
     for (int i = threadIdx.x; i < total; i += 1024) {
         const int j = i % F;
         const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j];
-        float v = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
+        float v = inv / m * (m * dv[i] * g - g * s_dy[j] - xv[i] * g * s_dyx[j]);
         if (act >= 0) v = v * act_grad(a[i], act);
         d[i] = v;
     }
@@ -2021,7 +2040,9 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
                                net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
         } else if (bn_small(n, F)) {        // small batch: statistics and normalisation in one single-block launch
-            hipLaunchKernelGGL(k_bn_small_fwd, 1, 1024, sizeof(float) * 2 * F, st, n, F, column_shift(F), h, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
+            static bool attr_fwd = false;
+            if (!attr_fwd) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bn_small_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); attr_fwd = true; }
+            hipLaunchKernelGGL(k_bn_small_fwd, 1, 1024, sizeof(float) * (2 * F + (size_t)n * F), st, n, F, column_shift(F), h, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
         } else if (n > 0) {
             const int64_t rpb = rows_per_block(n);
@@ -2086,7 +2107,9 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         float *p_dyx = net.part + net.g_off[2 * L], *p_dy = net.part + net.g_off[2 * L + 1];
         const bool fuse = net.rate[L] == 0.0f && act_last != GNN_ACT_SOFTMAX;
         if (!comm && bn_small(n, F)) {      // small batch: sums and d x in one single-block launch
-            hipLaunchKernelGGL(k_bn_small_bwd, 1, 1024, sizeof(float) * 2 * F, st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps, p_dyx, p_dy, ps, parts,
+            static bool attr_bwd = false;
+            if (!attr_bwd) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bn_small_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); attr_bwd = true; }
+            hipLaunchKernelGGL(k_bn_small_bwd, 1, 1024, sizeof(float) * (2 * F + (size_t)2 * n * F), st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps, p_dyx, p_dy, ps, parts,
                                c.a[L - 1], fuse ? act_last : -1);
             HIPCHK(hipGetLastError());
             last_act_done = fuse;
