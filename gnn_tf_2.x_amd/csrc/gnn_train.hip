@@ -319,82 +319,10 @@ __global__ void __launch_bounds__(256) k_bn_apply(int64_t n, int F, int cw_shift
     }
 }
 
-// BatchNormalization of a SMALL batch (n * F <= GNN_BN_SMALL elements: MUTAG-sized steps are launch-bound, 4 - 6 us per kernel whatever it
-// does) in ONE single-block launch instead of k_bn_stats + k_bn_apply: per column the rows are taken by 1024 / CW lanes in a fixed
-// interleave and the lane results merged in lane order (mean first, then the squared deviations: two passes like k_bn_stats), then the
-// same normalisation as k_bn_apply.  Dynamic LDS: 2 F floats.
-constexpr int64_t GNN_BN_SMALL = 12288;         // elements: the backward kernel keeps two copies in LDS (96 KB)
-inline bool bn_small(int64_t n, int F)
-{
-#ifdef GNN_DIAG
-    static const bool off = getenv("GNN_TRAIN_BN_SMALL") && atoi(getenv("GNN_TRAIN_BN_SMALL")) == 0;
-    if (off) return false;
-#endif
-    return n > 0 && n * F <= GNN_BN_SMALL;
-}
-// sum over the 1024 / CW lanes of column c (one value per lane) by a fixed binary tree in LDS (pairwise: the rounding error grows with
-// log n, not with n - a running sum of a few hundred gradient terms of both signs lost a digit against the chunked kernels); every
-// thread of the block calls it, every thread gets the column's sum
-__device__ __forceinline__ float bn_small_colsum(float v, float *red, int CW, int ZL, int c, int zl)
-{
-    __syncthreads();                                   // (the previous use of `red` is over)
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = ZL >> 1; s >= 1; s >>= 1) {
-        if (zl < s) red[zl * CW + c] += red[(zl + s) * CW + c];
-        __syncthreads();
-    }
-    return red[c];
-}
-// all n * F values of the block's matrix from memory into LDS with every load in flight at once (a single block that walks its rows with a
-// load per step is a chain of L2 latencies: 13 - 20 us per launch for a MUTAG batch, measured; staged: a few)
-__device__ __forceinline__ void bn_small_stage(const float *__restrict__ src, float *dst, int total)
-{
-    for (int i0 = 0; i0 < total; i0 += 8 * 1024) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + (int)threadIdx.x; t[u] = i < total ? src[i] : 0.0f; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + (int)threadIdx.x; if (i < total) dst[i] = t[u]; }
-    }
-}
-// dynamic LDS: 2 F + n F floats
-__global__ void __launch_bounds__(1024) k_bn_small_fwd(int64_t n, int F, int cw_shift, const float *__restrict__ h, float eps, const float *gamma, const float *beta,
-                                                       float *xhat, float *y, float *stats)
-{
-    extern __shared__ float bsh[];
-    __shared__ float red[1024];
-    float *sm = bsh, *sinv = bsh + F, *hv = bsh + 2 * F;
-    const int total = (int)(n * F);
-    bn_small_stage(h, hv, total);
-    const int CW = 1 << cw_shift, ZL = 1024 >> cw_shift;
-    const int c = threadIdx.x & (CW - 1), zl = threadIdx.x >> cw_shift;
-    for (int jb = 0; jb < F; jb += CW) {
-        const int j = jb + c;
-        float a0 = 0.0f;
-        __syncthreads();
-        if (j < F)
-            for (int r = zl; r < (int)n; r += ZL) a0 += hv[r * F + j];
-        const float m = bn_small_colsum(a0, red, CW, ZL, c, zl) / (float)n;
-        a0 = 0.0f;
-        if (j < F)
-            for (int r = zl; r < (int)n; r += ZL) { const float dv = hv[r * F + j] - m; a0 += dv * dv; }
-        const float var = bn_small_colsum(a0, red, CW, ZL, c, zl) / (float)n;
-        if (zl == 0 && j < F) {
-            sm[j] = m;
-            sinv[j] = 1.0f / sqrtf(var + eps);
-            stats[j] = m; stats[F + j] = var;
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < total; i += 1024) {
-        const int j = i % F;
-        const float xh = (hv[i] - sm[j]) * sinv[j];
-        xhat[i] = xh;
-        y[i] = gamma[j] * xh + beta[j];
-    }
-}
-
+// (Round 3 tried BatchNormalization of a small batch as ONE single-block launch per direction - statistics + apply, column sums + apply,
+//  matrices staged in LDS, tree-reduced column sums - to save two launches per call: SLOWER than the two multi-block kernels at MUTAG size,
+//  0.85 against 0.76 ms per 10-body step and 3.0 against 2.6 ms per 50-body step: one workgroup's latency chain against a few microseconds
+//  of launch.  Removed.)
 // ---- BatchNormalization statistics over the rows of ALL ranks (sharded training forward) ----------------------------------------------
 // k_bn_local: the rank's chunk statistics merged in chunk order into ONE triple per feature, tri = [count | mean | M2] (3 F floats);
 // the triples of all ranks are all-gathered (3 F floats per rank and call - the review's "2 H floats" plus the count) and
@@ -470,47 +398,6 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(int64_t n, int F, int cw_s
         const int j = small ? (int)((unsigned)i % (unsigned)F) : (int)(i % F);
         const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j];
         float v = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
-        if (act >= 0) v = v * act_grad(a[i], act);
-        d[i] = v;
-    }
-}
-
-// The backward pass of BatchNormalization for a small batch in one single-block launch (k_colreduce2 + k_bn_bwd_apply otherwise): the two
-// sums per column (they are also the gamma / beta gradients: written to chunk 0 of the partials, the other chunks' slots zeroed), then
-// d x and, fused, the derivative of the layer's activation.  Dynamic LDS: 2 F floats.
-// dynamic LDS: 2 F + 2 n F floats (d and xhat staged: bn_small_stage)
-__global__ void __launch_bounds__(1024) k_bn_small_bwd(int64_t n, int F, int cw_shift, float *d, const float *__restrict__ xhat, const float *gamma,
-                                                       const float *stats, float eps, float *p_dyx, float *p_dy, int64_t pstride, int parts,
-                                                       const float *__restrict__ a, int act)
-{
-    extern __shared__ float bsh[];
-    __shared__ float red[1024];
-    const int total = (int)(n * F);
-    float *s_dyx = bsh, *s_dy = bsh + F, *dv = bsh + 2 * F, *xv = dv + total;
-    bn_small_stage(d, dv, total);
-    bn_small_stage(xhat, xv, total);
-    const int CW = 1 << cw_shift, ZL = 1024 >> cw_shift;
-    const int c = threadIdx.x & (CW - 1), zl = threadIdx.x >> cw_shift;
-    for (int jb = 0; jb < F; jb += CW) {
-        const int j = jb + c;
-        float a0 = 0.0f, a1 = 0.0f;
-        __syncthreads();
-        if (j < F)
-            for (int r = zl; r < (int)n; r += ZL) { const float v = dv[r * F + j]; a0 += v * xv[r * F + j]; a1 += v; }
-        a0 = bn_small_colsum(a0, red, CW, ZL, c, zl);
-        a1 = bn_small_colsum(a1, red, CW, ZL, c, zl);
-        if (zl == 0 && j < F) {
-            s_dyx[j] = a0; s_dy[j] = a1;
-            p_dyx[j] = a0; p_dy[j] = a1;
-            for (int z = 1; z < parts; ++z) { p_dyx[(size_t)z * pstride + j] = 0.0f; p_dy[(size_t)z * pstride + j] = 0.0f; }
-        }
-    }
-    __syncthreads();
-    const float m = (float)n;
-    for (int i = threadIdx.x; i < total; i += 1024) {
-        const int j = i % F;
-        const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j];
-        float v = inv / m * (m * dv[i] * g - g * s_dy[j] - xv[i] * g * s_dyx[j]);
         if (act >= 0) v = v * act_grad(a[i], act);
         d[i] = v;
     }
@@ -2039,11 +1926,6 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
             hipLaunchKernelGGL(k_bn_apply_ext, n > 0 ? elementwise_grid(n * F) : 1, 256, sizeof(float) * 2 * F, st, n, F, h, tri_all, comm->world, m->eps, net.gamma,
                                net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
-        } else if (bn_small(n, F)) {        // small batch: statistics and normalisation in one single-block launch
-            static bool attr_fwd = false;
-            if (!attr_fwd) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bn_small_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); attr_fwd = true; }
-            hipLaunchKernelGGL(k_bn_small_fwd, 1, 1024, sizeof(float) * (2 * F + (size_t)n * F), st, n, F, column_shift(F), h, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
-            HIPCHK(hipGetLastError());
         } else if (n > 0) {
             const int64_t rpb = rows_per_block(n);
             const int parts = (int)cdiv(n, rpb);
@@ -2106,14 +1988,6 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         const int F = m->dims.back(), cs = column_shift(F);
         float *p_dyx = net.part + net.g_off[2 * L], *p_dy = net.part + net.g_off[2 * L + 1];
         const bool fuse = net.rate[L] == 0.0f && act_last != GNN_ACT_SOFTMAX;
-        if (!comm && bn_small(n, F)) {      // small batch: sums and d x in one single-block launch
-            static bool attr_bwd = false;
-            if (!attr_bwd) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bn_small_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); attr_bwd = true; }
-            hipLaunchKernelGGL(k_bn_small_bwd, 1, 1024, sizeof(float) * (2 * F + (size_t)2 * n * F), st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps, p_dyx, p_dy, ps, parts,
-                               c.a[L - 1], fuse ? act_last : -1);
-            HIPCHK(hipGetLastError());
-            last_act_done = fuse;
-        } else {
         hipLaunchKernelGGL(k_colreduce2, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, d, c.xhat, p_dyx, p_dy, ps, rpb);
         if (comm) {
             // this rank's sums [sum d y xhat | sum d y] (adjacent in the gradient vector: they ARE the gamma / beta gradients), those of
@@ -2130,7 +2004,6 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
                                p_dyx, p_dy, ps, parts, c.a[L - 1], fuse ? act_last : -1, (int64_t)0);
         HIPCHK(hipGetLastError());
         last_act_done = fuse;
-        }
     }
     if (net.rate[L] != 0.0f) {
         const int F = m->dims.back();
