@@ -48,6 +48,41 @@ def main():
             res[f'{layout}_{impl}_max'] = np.float64(comm.allreduce_max(float(rank + 1)))
             lp.close()
         comm.close()
+    # ---- LGNN.update_graph across the rank processes (gnn_graph_update_labels on an RCCL communicator: every rank relabels its rows, the
+    # label rows are all-gathered - whole shards, or boundary blocks on halo shards), then layer 1 on the relabelled graph
+    from util import make_mlp as _mk
+    rng1 = np.random.default_rng(31)
+    nl1 = g['nodes'].shape[1] + d + 2
+    st1 = _mk(rng1, 1 + 2 * (d + nl1), [16, d], 'selu', gain=0.6, bn_random=True)
+    ou1 = _mk(rng1, d + nl1, [2], 'softmax', bn_random=True)
+    s1 = (0.1 * rng1.standard_normal((n, d))).astype(np.float32)
+    for layout in ('full', 'halo'):
+        os.environ['GNN_BENCH_RDV'] = os.path.join(out_dir, f'id_lgnn_{layout}')
+        uid, _ = bench.rendezvous_id(rank, world, e)
+        comm = e.Comm(uid, rank, world, 0)
+        m0s, m0o = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+        m1s, m1o = e.Mlp(st1['weights'], st1['activations'], True), e.Mlp(ou1['weights'], ou1['activations'], True)
+        rb, nr, ip, src, w, aw, al_ = e.shard_csr(n, rank, world, indptr, adj_src, adj_w, arc_w, arc_lab)
+        if layout == 'halo':
+            h = e.shard_halo(n, rank, world, indptr, adj_src, g['nodes'])
+            base = e.Graph.halo(n, rank, world, h['block'], h['send_rows'], ip, h['adj_src'], w, aw, al_, h['nodes'], mask[rb:rb + nr])
+        else:
+            base = e.Graph(n, ip, src, w, aw, al_, g['nodes'], mask[rb:rb + nr], row_begin=rb)
+        l0 = e.Loop(base, m0s, m0o, d, 20, 0.01, comm)
+        l0.set_impl(1); l0.set_state0(s0[rb:rb + nr])
+        k0 = l0.run()
+        derived = base.derive(d + 2)
+        derived.update_labels(base, l0, True, True)
+        l1 = e.Loop(derived, m1s, m1o, d, 20, 0.01, comm)
+        l1.set_impl(1)
+        l1.set_state0(s1[rb:rb + nr])
+        k1 = l1.run()
+        res[f'lgnn_{layout}_k0'], res[f'lgnn_{layout}_k1'] = np.float64(k0), np.float64(k1)
+        res[f'lgnn_{layout}_labels'] = derived.nodes()[:nr] if layout == 'halo' else derived.nodes()[rb:rb + nr]
+        res[f'lgnn_{layout}_state'] = l1.state()
+        res[f'lgnn_{layout}_out'] = l1.output()
+        l1.close(); l0.close(); comm.close()
+
     # ---- training-mode forward on shards (gnn_loop_train_forward with world > 1): state rows all-gathered after every body, the
     # BatchNormalization statistics and the iteration gates those of all ranks.  Two cases: few rows (per-op kernels) and, MP_TRAIN_WIDE,
     # the wide-layer path.

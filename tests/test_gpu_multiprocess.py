@@ -74,6 +74,23 @@ def test_ranks_as_processes_match_oracle(world):
             assert {float(r[f'{layout}_{impl}_max']) for r in res} == {float(world)}      # gnn_comm_allreduce_max over the ranks
 
 
+    # ---- the two-layer LGNN stack with the relabelling between the layers across the rank processes, against the C oracle chain
+    from oracle import gnn_oracle as orc
+    from util import make_mlp as _mk
+    rng1 = np.random.default_rng(31)
+    nl1 = g['nodes'].shape[1] + d + 2
+    st1 = _mk(rng1, 1 + 2 * (d + nl1), [16, d], 'selu', gain=0.6, bn_random=True)
+    ou1 = _mk(rng1, d + nl1, [2], 'softmax', bn_random=True)
+    s1 = (0.1 * rng1.standard_normal((n, d))).astype(np.float32)
+    k0c, s0c, o0c = corc.loop_node(g, st, ou, d, 20, 0.01, s0)
+    g1 = orc.update_graph(g, s0c, o0c, True, True)
+    k1c, s1c, o1c = corc.loop_node(g1, st1, ou1, d, 20, 0.01, s1)
+    for layout in ('full', 'halo'):
+        assert {float(r[f'lgnn_{layout}_k0']) for r in res} == {float(k0c)} and {float(r[f'lgnn_{layout}_k1']) for r in res} == {float(k1c)}, layout
+        assert np.array_equal(np.concatenate([r[f'lgnn_{layout}_labels'] for r in res]), g1['nodes']), layout
+        assert np.array_equal(np.concatenate([r[f'lgnn_{layout}_state'] for r in res]), s1c), layout
+        assert np.array_equal(np.concatenate([r[f'lgnn_{layout}_out'] for r in res]), o1c), layout
+
     # ---- the training-mode forward on shards against the float64 oracle of the WHOLE graph (BatchNormalization over all rows) and
     # against the same forward on one GPU
     from oracle import gnn_train_oracle as tro
