@@ -48,6 +48,27 @@ def main():
             res[f'{layout}_{impl}_max'] = np.float64(comm.allreduce_max(float(rank + 1)))
             lp.close()
         comm.close()
+    # ---- the graph readout on shards (GNN.py:331-332; gnn_loop_readout on an RCCL communicator: per-rank partial [G, T], all-gathered, added in
+    # rank order) - all-true masks, graphs that straddle shard boundaries among them
+    gr_, stg, oug, s0g = S._case(911, 960, 8)
+    gr_['set_mask'] = np.ones(960, bool); gr_['output_mask'] = np.ones(960, bool)
+    rngg = np.random.default_rng(12)
+    bounds = np.sort(rngg.choice(np.arange(1, 960), 11, replace=False))
+    sizes = np.diff(np.concatenate([[0], bounds, [960]]))
+    ng_indptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ng_node, ng_w = np.arange(960, dtype=np.int32), np.repeat(1.0 / sizes, sizes).astype(np.float32)
+    ipg, srcg, wg, awg, alg = S._csr_parts(gr_)
+    os.environ['GNN_BENCH_RDV'] = os.path.join(out_dir, 'id_readout')
+    uid, _ = bench.rendezvous_id(rank, world, e)
+    comm = e.Comm(uid, rank, world, 0)
+    rb, nr, ip, src, w, aw, al_ = e.shard_csr(960, rank, world, ipg, srcg, wg, awg, alg)
+    grg = e.Graph(960, ip, src, w, aw, al_, gr_['nodes'], np.ones(nr, np.uint8), row_begin=rb)
+    lpg = e.Loop(grg, e.Mlp(stg['weights'], stg['activations'], True), e.Mlp(oug['weights'], oug['activations'], True), 8, 20, 0.01, comm)
+    lpg.set_impl(1); lpg.set_state0(s0g[rb:rb + nr])
+    res['readout_k'] = np.float64(lpg.run())
+    res['readout'] = lpg.readout(ng_indptr, ng_node, ng_w)
+    lpg.close(); comm.close()
+
     # ---- LGNN.update_graph across the rank processes (gnn_graph_update_labels on an RCCL communicator: every rank relabels its rows, the
     # label rows are all-gathered - whole shards, or boundary blocks on halo shards), then layer 1 on the relabelled graph
     from util import make_mlp as _mk

@@ -74,6 +74,21 @@ def test_ranks_as_processes_match_oracle(world):
             assert {float(r[f'{layout}_{impl}_max']) for r in res} == {float(world)}      # gnn_comm_allreduce_max over the ranks
 
 
+    # ---- graph readout on shards: every rank returns the same [G, T], the oracle's up to the rounding of graphs that straddle a shard boundary
+    gr_, stg, oug, s0g = S._case(911, 960, 8)
+    gr_['set_mask'] = np.ones(960, bool); gr_['output_mask'] = np.ones(960, bool)
+    rngg = np.random.default_rng(12)
+    bounds = np.sort(rngg.choice(np.arange(1, 960), 11, replace=False))
+    sizes = np.diff(np.concatenate([[0], bounds, [960]]))
+    ng_indptr = np.concatenate([[0], np.cumsum(sizes)])
+    kg, sg, og = corc.loop_node(gr_, stg, oug, 8, 20, 0.01, s0g)
+    node_graph = np.zeros((960, 12), np.float32)
+    for gi in range(12): node_graph[ng_indptr[gi]:ng_indptr[gi + 1], gi] = 1.0 / sizes[gi]
+    want = corc.readout(node_graph, og)
+    assert {float(r['readout_k']) for r in res} == {float(kg)}
+    assert all(np.array_equal(res[0]['readout'], r['readout']) for r in res[1:])
+    assert res[0]['readout'].shape == want.shape and np.max(np.abs(res[0]['readout'] - want)) < 1e-6
+
     # ---- the two-layer LGNN stack with the relabelling between the layers across the rank processes, against the C oracle chain
     from oracle import gnn_oracle as orc
     from util import make_mlp as _mk
