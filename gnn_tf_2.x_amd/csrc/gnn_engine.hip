@@ -1908,19 +1908,21 @@ extern "C" int gnn_loop_run_many(gnn_loop **loops, int n, float *k_out /* [n] */
     }
     std::vector<char> queued((size_t)n, 0);
     int rc = 0;
+    // (an error part-way: nothing queued is left running behind the caller's back)
+    auto drain = [&](int rc_) { for (int i = 0; i < n; ++i) if (queued[(size_t)i]) (void)hipStreamSynchronize(loops[i]->stream); return rc_; };
     for (int i = 0; i < n; ++i) {
         gnn_loop *l = loops[i];
         bool fused = false;
-        if ((rc = loop_prepare(l, &fused))) return rc;
+        if ((rc = loop_prepare(l, &fused))) return drain(rc);
         if (!(fused && gnn_small_supported(l))) continue;
         bool output_done = false;
         l->kfinal_host[1] = 0;
-        if ((rc = gnn_small_run(l, &output_done))) return rc;
-        if ((rc = loop_finish(l, false, output_done))) return rc;
+        if ((rc = gnn_small_run(l, &output_done))) return drain(rc);
         queued[(size_t)i] = 1;
+        if ((rc = loop_finish(l, false, output_done))) return drain(rc);
     }
     for (int i = 0; i < n; ++i)
-        if (!queued[(size_t)i] && (rc = run_loops(&loops[i], 1, &k_out[i]))) return rc;
+        if (!queued[(size_t)i] && (rc = run_loops(&loops[i], 1, &k_out[i]))) return drain(rc);
     for (int i = 0; i < n; ++i) {
         if (!queued[(size_t)i]) continue;
         gnn_loop *l = loops[i];
