@@ -1,0 +1,165 @@
+// Probe for DESIGN.md section 8 item 1: would rows in flight that cost no VGPRs (LDS-DMA into a ring) raise the rate of a gather that
+// shares its waves with a long matrix phase, as in k_fused?  One persistent workgroup of 8 waves per CU; every wave alternates, per "tile",
+//   a gather of ROWS random 256-byte rows of a 256 MB table (16 lanes x 16 B per row, accumulated into 4 registers per lane), and
+//   a matrix phase of MFMAS v_mfma_f32_32x32x16_bf16 on 128 accumulator registers (the register budget of k_fused's dense layers).
+// Variant R: register staging, 16 rows in flight per 16-lane group (64 per wave: 16 KiB), as k_fused does.
+// Variant D<B>: global_load_lds_dwordx4 into a per-wave LDS ring of B batches of 64 rows (B x 16 KiB in flight, no VGPRs), consumed with
+//   ds_read_b128 one batch behind.
+// hipcc --offload-arch=gfx950 -O3 -o gather_dma_probe gather_dma_probe.hip && ./gather_dma_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define GLOBAL __attribute__((address_space(1)))
+#define LDS __attribute__((address_space(3)))
+
+// VALU: vector-ALU instructions issued behind every MFMA (k_fused: about 8 per MFMA - activations, piece cutting)
+template <int VALU = 0>
+__device__ __forceinline__ void matrix_phase(f32x16 (&acc)[8], int mfmas, bf16x8 a, bf16x8 b, float (&v)[8] )
+{
+    for (int i = 0; i < mfmas; i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < VALU; ++q) v[q] = __builtin_fmaf(v[q], 1.0000001f, 0.5f);
+        }
+    }
+}
+
+// ROWS per tile and wave = BATCHES x 64
+template <int BATCHES, int VALU>
+__global__ void __launch_bounds__(512, 1) k_reg(const int *idx, int tiles, const float *table, float *out, int mfmas, int *ctr)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+    f32x16 acc[8];
+    for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(lane + i); b[i] = (__bf16)0.5f; }
+    v4f sum = {0, 0, 0, 0};
+    float vv[8];
+    for (int q = 0; q < 8; ++q) vv[q] = (float)(lane + q);
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(ctr, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= tiles) break;
+        const int *e = idx + (size_t)t * BATCHES * 64;
+        for (int bt = 0; bt < BATCHES; ++bt) {
+            v4f x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = *(const GLOBAL v4f *)(table + (size_t)e[bt * 64 + grp * 16 + u] * 64 + gl * 4);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sum += x[u];
+        }
+        matrix_phase<VALU>(acc, mfmas, a, b, vv);
+    }
+    float s = sum.x + sum.y + sum.z + sum.w;
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + vv[j];
+    if (s == 12345.678f) out[0] = s;
+}
+
+// the same with the rows DMA'd into an LDS ring of RING batches (16 KiB each) per wave
+template <int BATCHES, int RING>
+__global__ void __launch_bounds__(512, 1) k_dma(const int *idx, int tiles, const float *table, float *out, int mfmas, int *ctr)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & 15, grp = lane >> 4;
+    float *ring = lds + (size_t)wave * RING * 64 * 64;          // RING batches x 64 rows x 64 floats
+    f32x16 acc[8];
+    for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(float)(lane + i); b[i] = (__bf16)0.5f; }
+    v4f sum = {0, 0, 0, 0};
+    // one batch = 16 DMA instructions (each: 4 rows = 1 KiB contiguous in LDS, per-lane source address)
+    auto issue = [&](const int *e, int slot) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float *src = table + (size_t)e[grp * 16 + u] * 64 + gl * 4;
+            __builtin_amdgcn_global_load_lds((const GLOBAL void *)src, (LDS void *)(ring + ((size_t)slot * 64 + u * 4) * 64), 16, 0, 0);
+        }
+    };
+    auto consume = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += *(const v4f *)(ring + ((size_t)slot * 64 + u * 4 + grp) * 64 + gl * 4);
+    };
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(ctr, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= tiles) break;
+        const int *e = idx + (size_t)t * BATCHES * 64;
+        // fill the ring, then one batch consumed / one issued per step
+        for (int bt = 0; bt < RING && bt < BATCHES; ++bt) issue(e + bt * 64, bt);
+        for (int bt = 0; bt < BATCHES; ++bt) {
+            // wait until batch bt has landed: at most (min(RING, BATCHES - bt) - 1) batches = 16 x that many DMAs may still be in flight
+            const int later = (BATCHES - 1 - bt) < (RING - 1) ? (BATCHES - 1 - bt) : (RING - 1);
+            if (later >= 3) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            consume(bt % RING);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (bt + RING < BATCHES) issue(e + (bt + RING) * 64, bt % RING);
+        }
+        float vv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        matrix_phase<0>(acc, mfmas, a, b, vv);
+    }
+    float s = sum.x + sum.y + sum.z + sum.w;
+    for (int j = 0; j < 8; ++j) s += acc[j][0];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <class K>
+float timeit(K launch, int *ctr)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemset(ctr, 0, 4); hipDeviceSynchronize();
+    launch();
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        hipMemset(ctr, 0, 4); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    return best;
+}
+
+int main()
+{
+    const long N = 1000000;
+    constexpr int BATCHES = 5;                       // 320 rows per tile and wave: a 32-node tile of the benchmark graph (10 arcs per node)
+    const int tiles = 31250;
+    const long E = (long)tiles * BATCHES * 64;
+    std::vector<int> h(E);
+    srand(1);
+    for (long i = 0; i < E; ++i) h[i] = (int)(((long)rand() * 32768 + rand()) % N);
+    int *idx, *ctr; float *table, *out;
+    hipMalloc(&idx, E * 4); hipMalloc(&table, N * 256); hipMalloc(&out, 4096); hipMalloc(&ctr, 4);
+    hipMemcpy(idx, h.data(), E * 4, hipMemcpyHostToDevice);
+    hipMemset(table, 0, N * 256);
+    const double gb = (double)E * 256 / 1e9;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_dma<BATCHES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_dma<BATCHES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int mfmas : {0, 256, 504}) {
+        float t_r = timeit([&] { hipLaunchKernelGGL((k_reg<BATCHES, 0>), 256, 512, 1024, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
+        float t_v4 = timeit([&] { hipLaunchKernelGGL((k_reg<BATCHES, 4>), 256, 512, 1024, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
+        float t_v8 = timeit([&] { hipLaunchKernelGGL((k_reg<BATCHES, 8>), 256, 512, 1024, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
+        printf("mfmas per tile %3d, register staging: + 4 VALU per MFMA %.3f ms, + 8 VALU per MFMA %.3f ms\n", mfmas, t_v4, t_v8);
+        float t_1 = timeit([&] { hipLaunchKernelGGL((k_dma<BATCHES, 1>), 256, 512, 8 * 1 * 16384, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
+        float t_2 = -1.f;
+        // two batches per wave: 8 x 32 KiB = 256 KiB > 160 KiB of LDS: only with 4 waves per workgroup (not run); ring of 1 = same bytes in flight as R, no VGPRs
+        printf("mfmas per tile %3d: register staging %.3f ms (%.2f TB/s)   LDS-DMA ring of 1 batch %.3f ms (%.2f TB/s)\n", mfmas, t_r, gb / t_r, t_1, gb / t_1);
+        (void)t_2;
+    }
+    return 0;
+}
