@@ -63,6 +63,101 @@ __global__ void __launch_bounds__(512, 1) k_reg(const int *idx, int tiles, const
     if (s == 12345.678f) out[0] = s;
 }
 
+// register staging + k_fused's weight stream: per tile and wave `wloads` loads of 16 B per lane (1 KiB per wave-instruction) from a packed image of
+// img_kb KB that every wave of the chip reads in the same order (L2 / vector-L1 traffic, no HBM), one load per MFMA until they are used up,
+// consumed eight MFMAs later (the prefetch distance of k_fused)
+template <int BATCHES, int VALU>
+__global__ void __launch_bounds__(512, 1) k_regw(const int *idx, int tiles, const float *table, float *out, int mfmas, int *ctr, const v4f *img, int img_vec, int wloads)
+{
+    const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+    f32x16 acc[8];
+    for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    bf16x8 b;
+    for (int i = 0; i < 8; ++i) b[i] = (__bf16)0.5f;
+    v4f sum = {0, 0, 0, 0};
+    float vv[8];
+    for (int q = 0; q < 8; ++q) vv[q] = (float)(lane + q);
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(ctr, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= tiles) break;
+        const int *e = idx + (size_t)t * BATCHES * 64;
+        for (int bt = 0; bt < BATCHES; ++bt) {
+            v4f x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = *(const GLOBAL v4f *)(table + (size_t)e[bt * 64 + grp * 16 + u] * 64 + gl * 4);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sum += x[u];
+        }
+        v4f w[8];
+        int pos = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[j] = ((const GLOBAL v4f *)img)[(size_t)(pos % img_vec) * 64 + lane]; ++pos; }
+        for (int i = 0; i < mfmas; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, w[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+                if (pos < wloads) { w[j] = ((const GLOBAL v4f *)img)[(size_t)(pos % img_vec) * 64 + lane]; ++pos; }
+#pragma unroll
+                for (int q = 0; q < VALU; ++q) vv[q] = __builtin_fmaf(vv[q], 1.0000001f, 0.5f);
+            }
+        }
+    }
+    float s = sum.x + sum.y + sum.z + sum.w;
+    for (int j = 0; j < 8; ++j) s += acc[j][0] + vv[j];
+    if (s == 12345.678f) out[0] = s;
+}
+
+// The alternative tile shape: ONE wave per SIMD (4-wave workgroups, 512 VGPRs per wave), 64-node tiles - every weight fragment feeds TWO MFMAs (the two
+// 32-node halves of the tile), so the weight stream per node halves; two gather batches (32 KiB) in flight per wave keep the bytes in flight per CU.
+template <int BATCHES, int VALU>
+__global__ void __launch_bounds__(256, 1) k_wide(const int *idx, int tiles, const float *table, float *out, int mfmas, int *ctr, const v4f *img, int img_vec, int wloads)
+{
+    const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+    f32x16 acc[16];
+    for (int j = 0; j < 16; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    bf16x8 b0, b1;
+    for (int i = 0; i < 8; ++i) { b0[i] = (__bf16)0.5f; b1[i] = (__bf16)0.25f; }
+    v4f sum = {0, 0, 0, 0};
+    float vv[8];
+    for (int q = 0; q < 8; ++q) vv[q] = (float)(lane + q);
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(ctr, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= tiles) break;
+        const int *e = idx + (size_t)t * BATCHES * 64;
+        for (int bt = 0; bt < BATCHES; bt += 2) {          // two batches = 32 rows per lane group in flight
+            v4f x[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) x[u] = *(const GLOBAL v4f *)(table + (size_t)e[bt * 64 + (u >> 4) * 64 + grp * 16 + (u & 15)] * 64 + gl * 4);
+#pragma unroll
+            for (int u = 0; u < 32; ++u) sum += x[u];
+        }
+        v4f w[8];
+        int pos = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { w[j] = ((const GLOBAL v4f *)img)[(size_t)(pos % img_vec) * 64 + lane]; ++pos; }
+        for (int i = 0; i < mfmas; i += 16) {              // mfmas counts both halves: 2 per weight fragment
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, w[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc[j], 0, 0, 0);
+                acc[8 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc[8 + j], 0, 0, 0);
+                if (pos < wloads) { w[j] = ((const GLOBAL v4f *)img)[(size_t)(pos % img_vec) * 64 + lane]; ++pos; }
+#pragma unroll
+                for (int q = 0; q < 2 * VALU; ++q) vv[q & 7] = __builtin_fmaf(vv[q & 7], 1.0000001f, 0.5f);
+            }
+        }
+    }
+    float s = sum.x + sum.y + sum.z + sum.w;
+    for (int j = 0; j < 16; ++j) s += acc[j][0];
+    for (int j = 0; j < 8; ++j) s += vv[j];
+    if (s == 12345.678f) out[0] = s;
+}
+
 // the same with the rows DMA'd into an LDS ring of RING batches (16 KiB each) per wave
 template <int BATCHES, int RING>
 __global__ void __launch_bounds__(512, 1) k_dma(const int *idx, int tiles, const float *table, float *out, int mfmas, int *ctr)
@@ -148,6 +243,9 @@ int main()
     hipMemcpy(idx, h.data(), E * 4, hipMemcpyHostToDevice);
     hipMemset(table, 0, N * 256);
     const double gb = (double)E * 256 / 1e9;
+    v4f *img;
+    hipMalloc(&img, 282 * 1024);
+    hipMemset(img, 0, 282 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_dma<BATCHES, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_dma<BATCHES, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int mfmas : {0, 256, 504}) {
@@ -155,6 +253,14 @@ int main()
         float t_v4 = timeit([&] { hipLaunchKernelGGL((k_reg<BATCHES, 4>), 256, 512, 1024, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
         float t_v8 = timeit([&] { hipLaunchKernelGGL((k_reg<BATCHES, 8>), 256, 512, 1024, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
         printf("mfmas per tile %3d, register staging: + 4 VALU per MFMA %.3f ms, + 8 VALU per MFMA %.3f ms\n", mfmas, t_v4, t_v8);
+        if (mfmas == 504) {
+            for (int wl : {141, 282, 504}) {
+                float t_w = timeit([&] { hipLaunchKernelGGL((k_regw<BATCHES, 8>), 256, 512, 1024, 0, idx, tiles, table, out, mfmas, ctr, img, 282, wl); }, ctr);
+                printf("   + weight stream of %3d KiB per tile and wave (282 KB image, 8 VALU per MFMA): %.3f ms\n", wl, t_w);
+            }
+            float t_wide = timeit([&] { hipLaunchKernelGGL((k_wide<2 * BATCHES, 8>), 256, 256, 1024, 0, idx, tiles / 2, table, out, 2 * mfmas, ctr, img, 282, 282); }, ctr);
+            printf("   64-node tiles, one wave per SIMD (4-wave workgroups), 282 KiB of weights per 64 nodes, 32 KiB of rows in flight per wave: %.3f ms\n", t_wide);
+        }
         float t_1 = timeit([&] { hipLaunchKernelGGL((k_dma<BATCHES, 1>), 256, 512, 8 * 1 * 16384, 0, idx, tiles, table, out, mfmas, ctr); }, ctr);
         float t_2 = -1.f;
         // two batches per wave: 8 x 32 KiB = 256 KiB > 160 KiB of LDS: only with 4 waves per workgroup (not run); ring of 1 = same bytes in flight as R, no VGPRs
