@@ -36,6 +36,30 @@ for p in (ROOT, os.path.join(ROOT, 'gnn_tf_2.x_amd')):
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+class Watchdog:
+    """A rank that hangs inside a collective (a peer died, a wrong count or peer on some rank) must not hang the job: the ctypes calls
+    release the GIL, so a timer thread can end THIS process (exit code 124); the launcher - bench.py's own or torch.distributed.run -
+    then stops the other ranks and exits non-zero.  Fresh processes only, nothing is re-executed."""
+
+    def __init__(self, seconds, what, rank):
+        import threading
+        self.t = threading.Timer(seconds, self._fire)
+        self.t.daemon = True
+        self.what, self.rank, self.seconds = what, rank, seconds
+
+    def _fire(self):
+        print(f'bench.py: rank {self.rank}: "{self.what}" did not finish within {self.seconds:.0f} s - giving up (exit 124)', file=sys.stderr, flush=True)
+        os._exit(124)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
 def make_net(rng, n_in, widths, act, out_act=None, gain=1.0):
     """Random-init weights of the architecture (lecun_normal-like scale, as starter.py:52-54), BatchNormalization defaults.
     gain < 1 (other_configs only) makes the state map a contraction, so that Loops converge before max_iteration."""
@@ -129,6 +153,10 @@ def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0, full=None):
                          'max_abs_diff_state': float(np.max(np.abs(sg - s_orc))), 'max_abs_diff_output': float(np.max(np.abs(og_ - o_orc)))}
             del sg, og_
         out['gpu_vs_oracle_full_size'] = chk
+        # the verdict main() acts on: the exact path equals the oracle bit for bit (state, output, k) and the default path stops at the
+        # same k - at the workload's own size and depth (the oracle ran `iters` bodies; the default is the workload's max_iter)
+        ex, df = chk['exact_f32_mfma_path'], chk['default_split_bf16_path']
+        out['parity_ok'] = bool(ex['k_equal'] and ex['bit_identical_state'] and ex['max_abs_diff_output'] == 0.0 and df['k_equal'])
     del s_orc, o_orc
     if engine is not None:
         from GNN import GNN_utils as utils
@@ -309,7 +337,7 @@ def other_configs(engine, s, device=0):
 def profile_figures():
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC passes of this command
     (tools/profile.sh + tools/collect_profile.py -> profiles/<round>_pmc.json); None when no profile is committed."""
-    for tag in ('r03', 'r02', 'r01'):
+    for tag in ('r04', 'r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', f'{tag}_pmc.json')
         if os.path.exists(path):
             with open(path) as f:
@@ -339,7 +367,8 @@ def main():
                          'RCCL with more than one rank - until it has been, the bench keeps to the one-shot form)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the untimed configs[1] / configs[4] figures under config.other_configs')
-    ap.add_argument('--cpu-iters', type=int, default=20)
+    ap.add_argument('--cpu-iters', type=int, default=30, help='bodies of the CPU-baseline sample = depth of the full-size parity check (default: the workload\'s max_iter)')
+    ap.add_argument('--rank-timeout', type=float, default=900.0, help='N > 1: seconds a rank may spend in the timed / validation region before it gives up (exit 124)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:      # bare multi-GPU invocation: become the launcher (no GPU call in this process)
@@ -395,17 +424,53 @@ def main():
         engine._check(engine.lib().gnn_device_synchronize(local_rank))
         return comm.allreduce_max(value) if comm else value
 
-    for _ in range(args.warmup):
-        loop.run()
-    loop.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    k_total, iter_ms = 0.0, []
-    for _ in range(args.steps):
-        k_total += loop.run()
-        iter_ms.append(loop.timing()['avg_iter_ms'])
-    elapsed = barrier(time.perf_counter() - t0)          # device sync, then max over ranks
-    loop.set_profiling(False)
+    with Watchdog(args.rank_timeout if world > 1 else 3600.0, 'warm-up + timed Loops', rank):
+        for _ in range(args.warmup):
+            loop.run()
+        loop.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        k_total, iter_ms, gap_ms = 0.0, [], []
+        for _ in range(args.steps):
+            k_total += loop.run()
+            tm = loop.timing()
+            iter_ms.append(tm['avg_iter_ms'])
+            gap_ms.append(tm['avg_between_bodies_ms'])
+        elapsed = barrier(time.perf_counter() - t0)          # device sync, then max over ranks
+        loop.set_profiling(False)
+
+    # N > 1: the line must validate itself - nobody stands beside a driver's 8-GPU run.  Every rank runs 3 bodies of the SHARDED job and
+    # the same 3 bodies UNSHARDED on its own device (the whole graph fits one GPU) and compares its own rows: after three bodies a row
+    # depends on rows of every other rank (the synthetic graph has no locality), so a wrong peer, count or offset in any exchange shows
+    # in every rank's rows.  The largest difference over all ranks (allreduce max) and the agreement of k go into the line; the exact
+    # path (impl 1) must agree bit for bit, and so does the default path (a node's arithmetic does not depend on its tile).
+    sharded_check = None
+    if world > 1:
+        with Watchdog(args.rank_timeout, 'sharded-vs-unsharded validation', rank):
+            chk_impl = 1
+            lp_s = engine.Loop(graph, mst, mou, d, 3, 0.0, comm)
+            lp_s.set_impl(chk_impl)
+            lp_s.set_state0(state0[rb:rb + nr])
+            if args.exchange in ('slice', 'slice1'):
+                lp_s.set_slice_exchange(1 if args.exchange == 'slice1' else 2)
+            k_s = lp_s.run()
+            st_s, out_s = lp_s.state(), lp_s.output()
+            lp_s.close()
+            whole = engine.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8), device=local_rank)
+            lp_u = engine.Loop(whole, mst, mou, d, 3, 0.0)
+            lp_u.set_impl(chk_impl)
+            lp_u.set_state0(state0)
+            k_u = lp_u.run()
+            st_u, out_u = lp_u.state()[rb:rb + nr], lp_u.output()[rb:rb + nr]
+            lp_u.close(); whole.close()
+            diff = max(float(np.max(np.abs(st_s - st_u))) if nr else 0.0, float(np.max(np.abs(out_s - out_u))) if nr else 0.0)
+            k_bad = 0.0 if k_s == k_u else 1.0
+            diff_all, k_bad_all = comm.allreduce_max(diff), comm.allreduce_max(k_bad)
+            sharded_check = {'bodies': 3, 'impl': chk_impl, 'sharded_vs_unsharded_max_abs_diff': diff_all, 'k_equal': bool(k_bad_all == 0.0),
+                             'ok': bool(diff_all == 0.0 and k_bad_all == 0.0),
+                             'what': 'every rank: 3 bodies sharded vs the same 3 bodies unsharded on its own device, own rows of state and output, '
+                                     'bit-exact path; max over ranks'}
+            del st_s, out_s, st_u, out_u
 
     # the bit-exact fused path (impl 1) on the same inputs, one untimed + one timed Loop: reported beside the headline, and
     # the two final states are compared (the default path must stay within fp32 rounding noise of the exact one)
@@ -455,6 +520,7 @@ def main():
     loop.state(), loop.output()
     e2e_s = time.perf_counter() - t1
 
+    exit_code = 0
     if rank == 0:
         updates = n * k_total
         kernel_ms = float(np.mean(iter_ms))
@@ -471,7 +537,7 @@ def main():
             'metric': 'node-state-updates/sec (nodes x iters / s), 1M-node synthetic graph',
             'value': updates / elapsed, 'unit': 'node-state-updates/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'synthetic randomGraph-recipe graph, N={n} nodes, E={e} arcs, state_dim=64, '
                                    f'net_state 135->128->128->64 selu+BN, net_output 67->2 softmax+BN, '
                                    f'max_iter={args.max_iter}, threshold=0 (all iterations run); the loop-invariant label aggregates '
@@ -491,17 +557,51 @@ def main():
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': kernel_ms},
         }
         if pf:      # counters of the same kernel from the committed PMC passes (north_star: HBM GB/s and MFMA-busy against gfx950 peak)
-            line['roofline'].update({k: pf[k] for k in ('mfma_busy_pct', 'valu_busy_pct', 'lds_bank_conflict_share', 'valu_insts_per_tile',
-                                                        'effective_clock_ghz', 'profiled_avg_launch_ms') if k in pf})
+            # They are a COPY of profiles/<round>_pmc.json (separate --pmc passes of this command), not measured in this run: they only
+            # stand when the profiled build is the one running, i.e. when its launch time matches the live one within 5 %.
+            line['roofline']['counters_from_committed_profile'] = True
+            prof_ms = pf.get('profiled_avg_launch_ms')
+            stale = prof_ms is None or kernel_ms <= 0 or abs(prof_ms - kernel_ms) > 0.05 * kernel_ms
+            line['roofline']['profiled_avg_launch_ms'] = prof_ms
+            if stale:
+                line['roofline']['traffic'] = None
+                line['roofline']['counters_dropped'] = (f'profiled launch {prof_ms} ms vs live {kernel_ms:.4f} ms differ by more than 5 %: the committed '
+                                                        f'counters describe another build; re-run tools/profile.sh')
+            else:
+                line['roofline'].update({k: pf[k] for k in ('mfma_busy_pct', 'valu_busy_pct', 'lds_bank_conflict_share', 'valu_insts_per_tile',
+                                                            'effective_clock_ghz') if k in pf})
+        if world > 1:      # what an iteration of the sharded job is made of, and the self-check of the exchange
+            recv = {'full': (world - 1) * (n // world) * d * 4, 'slice': 2 * (world - 1) * (n // world) * (d // world) * 4 if d % world == 0 else None,
+                    'slice1': 2 * (world - 1) * (n // world) * (d // world) * 4 if d % world == 0 else None, 'halo': None}[args.exchange]
+            line['multi_gpu'] = {'exchange': args.exchange, 'kernel_ms_per_iteration': kernel_ms, 'exchange_ms_per_iteration': float(np.mean(gap_ms)),
+                                 'bytes_received_per_rank_per_iteration': recv,
+                                 'what': 'rank 0, HIP events on the loop stream: kernel = the fused iteration kernel of the owned rows; exchange = everything '
+                                         'between the end of one body\'s kernel and the start of the next (all-gather of rows + flags, or the sliced '
+                                         'layout\'s pack / all-to-all / aggregation / all-to-all / unpack)',
+                                 'sharded_check': sharded_check}
         if world == 1 and not args.no_other_configs and args.nodes == 1_000_000:
-            line['config']['other_configs'] = other_configs(engine, s, local_rank)
+            try:             # untimed extras: whatever happens there must not cost the headline line
+                line['config']['other_configs'] = other_configs(engine, s, local_rank)
+            except Exception as ex:      # noqa: BLE001
+                line['config']['other_configs'] = {'error': repr(ex)}
+        parity_ok = None
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters, engine, local_rank, full=(graph, mst, mou))
+            parity_ok = line['cpu_baseline'].pop('parity_ok', None)
+        if world > 1:
+            parity_ok = sharded_check['ok']
+        line['parity_ok'] = parity_ok       # null: not checked in this invocation (--no-cpu-baseline)
         print(json.dumps(line), flush=True)
+        if parity_ok is False:
+            print('bench.py: PARITY FAILED - ' + ('the sharded run differs from the unsharded one' if world > 1 else
+                  'the GPU result differs from the oracle at full size (cpu_baseline.gpu_vs_oracle_full_size)'), file=sys.stderr, flush=True)
+            exit_code = 3
     if comm:
         barrier()
         if rank == 0 and id_path and os.path.exists(id_path):
             os.remove(id_path)
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == '__main__':

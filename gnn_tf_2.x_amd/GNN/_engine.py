@@ -20,7 +20,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_reset_optimizer', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loop_update_moving_statistics', 'gnn_loss_grad',
-           'gnn_counters_get', 'gnn_lgnn_run', 'gnn_loop_run_many', 'gnn_loop_set_impl', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_destroy', 'gnn_shard_range',
+           'gnn_counters_get', 'gnn_lgnn_run', 'gnn_loop_run_many', 'gnn_loop_set_impl', 'gnn_loop_gate_info', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_get_exchange_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
            'gnn_comm_create_loopback', 'gnn_graph_set_full_adjacency', 'gnn_loop_set_slice_exchange', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
 
@@ -475,10 +475,13 @@ class Loop:
         return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
                     bn_batch_state=bns[:kk], bn_batch_output=bno)
 
-    def set_slice_exchange(self, on=True):
-        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows.  on = True / 1: the return
-        all-to-all runs block by block beside the aggregation (second stream); on = 2: whole slice, then one all-to-all."""
-        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(int(on))))
+    def set_slice_exchange(self, on=2):
+        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows.  on = 2 (the default, also for
+        True): whole slice, then one grouped all-to-all; on = 1: the return all-to-all runs block by block beside the aggregation on a second
+        stream of the communicator - bit-identical in loopback groups and over the tests' stand-in transport, but not the default until it has
+        run once over RCCL with more than one rank; on = 0 / False: off."""
+        form = 2 if on is True else int(on)
+        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(form)))
 
     def update_moving_statistics(self, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
         """gnn_loop_update_moving_statistics: the moving statistics of both nets from the last train_forward, on the device."""
@@ -559,6 +562,13 @@ class Loop:
         _check(lib().gnn_loop_set_impl(self._h, C.c_int(impl), C.byref(used)))
         return used.value
 
+    def gate_info(self) -> tuple:
+        """gnn_loop_gate_info: (the last run was repeated on the bit-exact path because a gate of the default path was not certified, how
+        often that has happened on this loop)."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().gnn_loop_gate_info(self._h, C.byref(a), C.byref(b)))
+        return bool(a.value), int(b.value)
+
     def set_persistent(self, enable: bool) -> bool:
         """gnn_loop_set_persistent: allow / forbid the one-launch-per-Loop path of small graphs; returns whether it will be used."""
         used = C.c_int(0)
@@ -624,7 +634,9 @@ class Loop:
     def timing(self):
         tot, avg, n = C.c_float(), C.c_float(), C.c_int()
         _check(lib().gnn_loop_get_timing(self._h, C.byref(tot), C.byref(avg), C.byref(n)))
-        return dict(total_ms=tot.value, avg_iter_ms=avg.value, n_iter_timed=n.value)
+        gap = C.c_float()
+        _check(lib().gnn_loop_get_exchange_timing(self._h, C.byref(gap)))
+        return dict(total_ms=tot.value, avg_iter_ms=avg.value, n_iter_timed=n.value, avg_between_bodies_ms=gap.value)
 
     def state(self) -> np.ndarray:
         out = np.empty((self.n_rows, self.Ds), dtype=np.float32)

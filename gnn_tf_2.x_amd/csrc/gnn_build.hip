@@ -68,7 +68,7 @@ struct Scratch {
     int get(T **out, size_t count)
     {
         *out = nullptr;
-        if (hipMalloc((void **)out, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
+        if (gnn_dev_malloc((void **)out, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
         p.push_back(*out);
         return GNN_OK;
     }
@@ -79,7 +79,7 @@ template <typename T>
 int keep(T **dst, size_t count)
 {
     *dst = nullptr;
-    if (hipMalloc((void **)dst, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
+    if (gnn_dev_malloc((void **)dst, std::max<size_t>(1, count) * sizeof(T)) != hipSuccess) return gnn_fail(GNN_ERR_HIP, "hipMalloc of %zu bytes failed", count * sizeof(T));
     return GNN_OK;
 }
 

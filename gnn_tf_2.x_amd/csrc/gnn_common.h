@@ -9,6 +9,14 @@
 
 int gnn_fail(int code, const char *fmt, ...);
 
+// Every device allocation of the library goes through here.  Shipped build: hipMalloc.  Diagnostic build (make DIAG=1) with GNN_POISON=1
+// in the environment: the block is filled with 0xFF bytes (a quiet NaN as float, -1 as int) and the fill has COMPLETED before the call
+// returns, so a kernel that reads a word nobody wrote produces a NaN / a wild index instead of whatever the previous owner of the
+// memory left there (gnn_engine.hip).  The same switch makes k_fused / k_small_loop / k_small16 write NaN over their whole LDS
+// allocation before their first tile.
+hipError_t gnn_dev_malloc(void **p, size_t bytes);
+bool gnn_poison_enabled();
+
 #define HIPCHK(expr)                                                                             \
     do {                                                                                         \
         hipError_t e_ = (expr);                                                                  \
@@ -100,6 +108,31 @@ __device__ __forceinline__ void gnn_flag_raise(int *flag_rank_base)
 {
     int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;
     if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(w, 1);
+}
+
+// Certified gate of the split-arithmetic path (impl 2; reference GNN/GNN.py:206-220: `distance > threshold * norm`, reduce_any).
+// The states of impl 2 differ from the bit-exact chain (impl 1) in the last bits, so a node whose test sits ON the threshold could
+// be decided differently by the two - and with it k.  Besides the gate word (word 0 of its slot's line) the split path therefore
+// raises, per body,
+//     word 1  "some node moves ROBUSTLY":  distance >  threshold * norm + band
+//     word 2  "some node is BORDERLINE":  |distance - threshold * norm| <= band,      band = ABS * norm + REL * threshold * norm.
+// A gate is certified when a robust mover exists (open under either arithmetic) or no node is borderline (every node decided by a
+// margin); k_finalize reports a gate that is neither, and the host then repeats that Loop on impl 1 and returns ITS k / state / output
+// (run_loops).  The band is far wider than the measured state difference of the two paths near convergence (<= 2e-6 relative:
+// tests/test_gpu_parity.py), and it only matters for the body at which a loop stops - where, by definition, nothing moves robustly.
+#define GNN_BAND_ABS 1e-5f
+#define GNN_BAND_REL 1e-3f
+__device__ __forceinline__ void gnn_flag_raise_certified(int *flag_rank_base, bool moved, bool robust, bool border)
+{
+    int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;
+    if (!(moved || border)) return;                  // (robust implies moved)
+    // the three words of the line are requested together (L1-bypassing loads, as gnn_flag_raise): one wait, then only the missing ORs
+    const int c0 = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c1 = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int c2 = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (moved && c0 == 0) atomicOr(w, 1);
+    if (robust && c1 == 0) atomicOr(w + 1, 1);
+    if (border && c2 == 0) atomicOr(w + 2, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -221,7 +254,9 @@ struct gnn_loop {
     float *feats = nullptr, *out = nullptr, *otmp[2] = {nullptr, nullptr};
     int *flags = nullptr;                   // [(max_iter+2), world, GNN_FLAG_WORDS]
     int *tile_ctr = nullptr;                // fused path: one tile counter per iteration [max_iter + 1]
-    int *kfinal_dev = nullptr, *kfinal_host = nullptr;   // device [4]: k, persistent-loop barrier counter, its status word, pad; host mirror [4]
+    int *kfinal_dev = nullptr, *kfinal_host = nullptr;   // device [4]: k, status word of the persistent loop, "a gate of this run is not certified" (impl 2), pad; host mirror [4]
+    int certified_reruns = 0;               // Loops of this handle that were repeated on impl 1 because a gate of the impl-2 run was not certified
+    bool last_run_rerun = false;
     bool small_words_clean = false;         // the double-buffered gate words of the persistent loop are zero / in their run-parity state
     unsigned small_runs = 0;
     float *small_xs = nullptr;              // the persistent loop's padded exchange rows (gnn_small.hip), allocated with its first run
@@ -239,6 +274,9 @@ struct gnn_loop {
     float *ng_host = nullptr;
     int ng_G = 0, ng_host_floats = 0;
     bool ng_inlaunch = false;
+    // l->out is rewritten by every run - inference (loop_prepare) AND training (train_forward): the folded readout in ng_host is only valid
+    // for the run whose number it carries (gnn_loop_ng_folded)
+    uint64_t out_runs = 0, ng_inlaunch_run = 0;
     // edge-based readout (GNNedgeBased.apply_filters): entry -> CSR row, arc labels in original order, masked arc list
     bool edge_mode = false, edge_expected = false;
     int32_t *edge_dst = nullptr, *edge_rows = nullptr;
@@ -252,6 +290,7 @@ struct gnn_loop {
     std::vector<hipEvent_t> ev;
     hipEvent_t ev_total[2] = {nullptr, nullptr};
     float total_ms = 0.f, avg_iter_ms = 0.f;
+    float avg_gap_ms = 0.f;                 // profiling: mean time on the stream BETWEEN the end of body k's kernel(s) and the start of body k + 1's: the exchange (+ pack / aggregate / unpack of the sliced layout)
     int n_iter_timed = 0;
     // feature-sliced exchange (gnn_loop_set_slice_exchange): rank q aggregates columns [q Cs, (q + 1) Cs) of the state for ALL nodes
     bool slice_mode = false;
@@ -268,6 +307,9 @@ struct gnn_loop {
     void *train_arena = nullptr;            // gnn_train.hip: device scratch slabs kept from step to step
     int train_k_hint = 0;                   // bodies the last training forward of this loop ran (the next one enqueues that many + 1 before it looks at the gates)
 };
+
+// the graph readout of the loop's LAST run was computed inside that run's persistent launch (result in ng_host)
+inline bool gnn_loop_ng_folded(const gnn_loop *l) { return l->ng_inlaunch && l->ng_inlaunch_run == l->out_runs; }
 
 // gnn_engine.hip
 int gnn_graph_wait_ready(const gnn_graph *g, hipStream_t st);

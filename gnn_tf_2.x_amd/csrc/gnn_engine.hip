@@ -57,12 +57,39 @@ extern "C" int gnn_device_synchronize(int device)
     return GNN_OK;
 }
 
+bool gnn_poison_enabled()
+{
+#ifdef GNN_DIAG
+    static const bool on = [] {
+        const bool v = getenv("GNN_POISON") != nullptr && atoi(getenv("GNN_POISON")) != 0;
+        if (v) fprintf(stderr, "libgnn_hip (diagnostic build): GNN_POISON=1 - every device allocation and the fused kernels' LDS are filled with NaN before use\n");
+        return v;
+    }();
+    return on;
+#else
+    return false;
+#endif
+}
+
+hipError_t gnn_dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+#ifdef GNN_DIAG
+    if (e == hipSuccess && gnn_poison_enabled()) {
+        // null-stream fill + device-wide wait: complete before ANY stream of the engine can touch the block (diagnostic build only)
+        e = hipMemset(*p, 0xFF, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+#endif
+    return e;
+}
+
 template <typename T>
 static int dev_alloc(T **p, size_t count)
 {
     *p = nullptr;
     if (count == 0) count = 1;
-    HIPCHK(hipMalloc((void **)p, count * sizeof(T)));
+    HIPCHK(gnn_dev_malloc((void **)p, count * sizeof(T)));
     return GNN_OK;
 }
 
@@ -328,6 +355,19 @@ __global__ void k_finalize(const int *flags, int world, int max_iter, int *kfina
         if (m) { k_final = k0 + __builtin_ctzll(m); break; }
     }
     if (lane == 0) *kfinal = k_final;
+    // certified gate of the split-arithmetic path (gnn_common.h, gnn_flag_raise_certified): gates 1 .. k_final that decided this run (the
+    // gate of body max_iter is never consulted; gate 0 is the first condition, the same arithmetic on every path).  Not certified: no node
+    // moved robustly AND some node was borderline.  The exact paths never raise words 1 / 2, so this stays 0 for them.
+    int amb = 0;
+    const int last = k_final < max_iter ? k_final : max_iter - 1;
+    for (int k = 1 + lane; k <= last; k += 64) {
+        const int *gate = flags + (size_t)k * world * GNN_FLAG_WORDS;
+        int robust = 0, border = 0;
+        for (int p = 0; p < world * GNN_FLAG_SLOTS; ++p) { robust |= gate[p * GNN_FLAG_STRIDE + 1]; border |= gate[p * GNN_FLAG_STRIDE + 2]; }
+        amb |= (!robust && border) ? 1 : 0;
+    }
+    amb = __any(amb) ? 1 : 0;
+    if (lane == 0) kfinal[2] = amb;
 }
 
 // apply_filters(): feats[m] = [state_final[row_m] | nodes[row_m] (iff D > 0)]
@@ -1134,7 +1174,7 @@ extern "C" int gnn_comm_create(const uint8_t id[128], int rank, int world, int d
     memcpy(uid.b, id, 128);
     int r = g_rccl.CommInitRank(&c->nccl, world, uid, rank);
     if (r != 0) { delete c; return gnn_fail(GNN_ERR_COMM, "ncclCommInitRank -> %s", g_rccl.GetErrorString(r)); }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&c->scratch, sizeof(double)) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || gnn_dev_malloc((void **)&c->scratch, sizeof(double)) != hipSuccess) {
         gnn_comm_destroy(c);
         return gnn_fail(GNN_ERR_HIP, "communicator stream / scratch allocation failed");
     }
@@ -1264,10 +1304,10 @@ extern "C" int gnn_loop_create(gnn_graph *g, gnn_mlp *net_state, gnn_mlp *net_ou
         if (!rc) rc = zero_on_stream(l->state[b], sizeof(float) * (size_t)l->N_pad * Ds, l->stream);      // ordered before everything this loop ever queues
     }
     if (!rc) rc = dev_alloc(&l->flags, (size_t)(max_iter + 2) * world * GNN_FLAG_WORDS + 4);   // + barrier counter / status of the persistent loop
-    if (!rc) rc = dev_alloc(&l->kfinal_dev, 2);        // k, status word of the persistent loop
+    if (!rc) rc = dev_alloc(&l->kfinal_dev, 4);        // k, status word of the persistent loop, "gate not certified", pad
     if (!rc) rc = dev_alloc(&l->tile_ctr, (2 * ((size_t)max_iter + 1) + 3) & ~(size_t)3);      // one ticket counter per body (the second half is spare: a partial last tile used to get a launch of its own)
-    if (!rc && hipHostMalloc((void **)&l->kfinal_host, 2 * sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
-    if (!rc) l->kfinal_host[1] = 0;
+    if (!rc && hipHostMalloc((void **)&l->kfinal_host, 4 * sizeof(int)) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
+    if (!rc) l->kfinal_host[1] = l->kfinal_host[2] = 0;
     if (!rc && hipHostMalloc((void **)&l->gate_host, sizeof(int) * (size_t)world * GNN_FLAG_WORDS) != hipSuccess) rc = gnn_fail(GNN_ERR_HIP, "hipHostMalloc");
     if (!edge_width) {      // the edge-based buffers are sized in gnn_loop_set_edge_readout
         if (!rc) rc = dev_alloc(&l->feats, (size_t)g->n_masked * l->wf);
@@ -1299,6 +1339,14 @@ extern "C" int gnn_loop_set_impl(gnn_loop *l, int impl, int *used)
     ARGCHK(l && impl >= 0 && impl <= 2, "impl must be 0 (unfused), 1 (fused, exact f32 MFMA) or 2 (fused, split bf16 MFMA)");
     l->impl_req = impl;
     if (used) *used = (impl >= 1 && gnn_fused_supported(l)) ? impl : 0;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_gate_info(const gnn_loop *l, int *last_run_repeated, int *repeats_total)
+{
+    ARGCHK(l, "loop is NULL");
+    if (last_run_repeated) *last_run_repeated = l->last_run_rerun ? 1 : 0;
+    if (repeats_total) *repeats_total = l->certified_reruns;
     return GNN_OK;
 }
 
@@ -1334,6 +1382,14 @@ extern "C" int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *av
     if (total_ms) *total_ms = l->total_ms;
     if (avg_iter_ms) *avg_iter_ms = l->avg_iter_ms;
     if (n_iter_timed) *n_iter_timed = l->n_iter_timed;
+    return GNN_OK;
+}
+
+extern "C" int gnn_loop_get_exchange_timing(const gnn_loop *l, float *avg_between_bodies_ms)
+{
+    ARGCHK(l && avg_between_bodies_ms, "bad arguments");
+    if (!l->ran) return gnn_fail(GNN_ERR_STATE, "gnn_loop_run has not been called");
+    *avg_between_bodies_ms = l->avg_gap_ms;
     return GNN_OK;
 }
 
@@ -1735,7 +1791,10 @@ static int loop_finish(gnn_loop *l, bool finalize, bool output_done)
         hipLaunchKernelGGL(k_finalize, 1, 64, 0, st, l->flags, l->world, l->max_iter, l->kfinal_dev);
         HIPCHK(hipGetLastError());
     }
-    if (finalize) HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (finalize) {
+        HIPCHK(hipMemcpyAsync(l->kfinal_host, l->kfinal_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(l->kfinal_host + 2, l->kfinal_dev + 2, sizeof(int), hipMemcpyDeviceToHost, st));      // "a gate was not certified"
+    }
     if (output_done) return GNN_OK;     // (the persistent loop wrote k into the pinned host words and ran the output stage itself)
     const float *own0 = l->state[0] + (size_t)l->own_off * l->Ds, *own1 = l->state[1] + (size_t)l->own_off * l->Ds;
     const float *nodes_own = g->nodes + (size_t)g->own_off * g->NL;
@@ -1779,6 +1838,7 @@ static int loop_prepare(gnn_loop *l, bool *fused_out)
         return gnn_fail(GNN_ERR_STATE, "net_output has the edge-based input width: call gnn_loop_set_edge_readout first");
     HIPCHK(hipSetDevice(l->device));
     l->ng_inlaunch = false;          // (set again by gnn_small_run when it folds the graph readout into its launch)
+    ++l->out_runs;                   // this run rewrites l->out: a readout folded into an earlier launch is stale from here on
     if (!l->graph_ready_seen) {      // a derived graph's creation-time fills (gnn_graph_derive) come before the first read of its labels
         int rcw = gnn_graph_wait_ready(l->g, l->stream);
         if (rcw) return rcw;
@@ -1814,6 +1874,15 @@ static int loop_collect(gnn_loop *l, float *k_out)
         }
         l->n_iter_timed = l->kfinal;
         l->avg_iter_ms = l->kfinal ? (float)(sum / l->kfinal) : 0.f;
+        // what sits between two bodies on the stream: the exchange of the sharded layouts (all-gather of rows / boundary rows + flags, or
+        // pack -> all-to-all -> slice aggregation -> all-to-all -> unpack), a few microseconds of launch gap on a single GPU
+        double gap = 0;
+        for (int k = 0; k + 1 < l->kfinal; ++k) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, l->ev[2 * k + 1], l->ev[2 * k + 2]));
+            gap += ms;
+        }
+        l->avg_gap_ms = l->kfinal > 1 ? (float)(gap / (l->kfinal - 1)) : 0.f;
     }
     if (k_out) *k_out = (float)l->kfinal;
     return GNN_OK;
@@ -1876,6 +1945,16 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
         ls[0]->small_words_clean = false;
         return run_loops(ls, n, k_out);
     }
+    // Certified gate (gnn_common.h): a gate of this impl-2 run was decided by a borderline node and no robust mover - its k is not
+    // guaranteed to be the bit-exact chain's.  The Loop is repeated on impl 1 and THAT run's k / state / output are what the caller gets.
+    // Every rank reads the same exchanged flag words, so all ranks of a sharded job take this branch together.
+    for (int r = 0; r < n; ++r) ls[r]->last_run_rerun = false;
+    if (!small && fused[0] && ls[0]->impl_req == 2 && ls[0]->kfinal_host[2] != 0) {
+        for (int r = 0; r < n; ++r) ls[r]->impl_req = 1;
+        rc = run_loops(ls, n, k_out);
+        for (int r = 0; r < n; ++r) { ls[r]->impl_req = 2; ls[r]->last_run_rerun = true; ++ls[r]->certified_reruns; }
+        return rc;
+    }
     for (int r = 0; r < n; ++r) {
         float k = 0.f;
         if ((rc = loop_collect(ls[r], &k))) return rc;
@@ -1906,38 +1985,59 @@ extern "C" int gnn_loop_run_many(gnn_loop **loops, int n, float *k_out /* [n] */
         ARGCHK(loops[i]->world == 1, "loop %d is one rank of a sharded job: gnn_loop_run / gnn_loop_run_group", i);
         for (int j = 0; j < i; ++j) ARGCHK(loops[j] != loops[i], "loop %d is listed twice", i);
     }
-    std::vector<char> queued((size_t)n, 0);
+    std::vector<char> queued((size_t)n, 0), done((size_t)n, 0);
     int rc = 0;
-    // (an error part-way: nothing queued is left running behind the caller's back)
-    auto drain = [&](int rc_) { for (int i = 0; i < n; ++i) if (queued[(size_t)i]) (void)hipStreamSynchronize(loops[i]->stream); return rc_; };
+    // (an error part-way: nothing queued is left running behind the caller's back - EVERY early return below goes through drain)
+    auto drain = [&](int rc_) { for (int i = 0; i < n; ++i) if (queued[(size_t)i] && !done[(size_t)i]) (void)hipStreamSynchronize(loops[i]->stream); return rc_; };
+    // Residency: the persistent launches synchronise through a grid barrier, so every workgroup of every launch in flight must be
+    // resident at once.  A launch's workgroup is one wave with 10 - 40 KB of LDS: at least four fit on a CU; launches are queued side by
+    // side only while their workgroups sum to no more than three per CU, then the queued ones are collected before the next is queued
+    // (the barrier's spin time-out stays as the safety net, it is no longer the mechanism).
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, loops[0]->device) != hipSuccess || n_cu <= 0) n_cu = 64;
+    const long cap = 3L * n_cu;
+    long in_flight = 0;
+    // wait for the queued launches and take their results; one whose barrier gave up runs again, alone, one launch per body
+    auto collect = [&]() -> int {
+        int first_rc = GNN_OK;
+        for (int i = 0; i < n; ++i) {
+            if (!queued[(size_t)i] || done[(size_t)i]) continue;
+            gnn_loop *l = loops[i];
+            hipError_t e = hipSetDevice(l->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(l->stream);
+            done[(size_t)i] = 1;
+            if (e != hipSuccess) { if (!first_rc) first_rc = gnn_fail(GNN_ERR_HIP, "hipStreamSynchronize -> %s", hipGetErrorString(e)); continue; }
+            if (first_rc) continue;                  // (keep waiting for the others, report the first error)
+            int r = GNN_OK;
+            if (l->kfinal_host[1] != 0) {            // a barrier spin gave up: this one again, alone, one launch per body
+                l->ng_inlaunch = false;
+                l->small_disabled = true;
+                l->small_words_clean = false;
+                r = run_loops(&loops[i], 1, &k_out[i]);
+                l->small_disabled = false;           // (alone it would have been resident: only this call falls back)
+            } else r = loop_collect(l, &k_out[i]);
+            if (r) first_rc = r;
+        }
+        in_flight = 0;
+        return first_rc;
+    };
     for (int i = 0; i < n; ++i) {
         gnn_loop *l = loops[i];
         bool fused = false;
         if ((rc = loop_prepare(l, &fused))) return drain(rc);
         if (!(fused && gnn_small_supported(l))) continue;
+        const long wgs = (long)((l->g->n_rows + 15) / 16);      // upper bound of the launch's grid (16- or 32-node tiles)
+        if (in_flight && in_flight + wgs > cap && (rc = collect())) return drain(rc);
         bool output_done = false;
         l->kfinal_host[1] = 0;
         if ((rc = gnn_small_run(l, &output_done))) return drain(rc);
         queued[(size_t)i] = 1;
+        in_flight += wgs;
         if ((rc = loop_finish(l, false, output_done))) return drain(rc);
     }
     for (int i = 0; i < n; ++i)
         if (!queued[(size_t)i] && (rc = run_loops(&loops[i], 1, &k_out[i]))) return drain(rc);
-    for (int i = 0; i < n; ++i) {
-        if (!queued[(size_t)i]) continue;
-        gnn_loop *l = loops[i];
-        HIPCHK(hipSetDevice(l->device));
-        HIPCHK(hipStreamSynchronize(l->stream));
-        if (l->kfinal_host[1] != 0) {          // a barrier spin gave up (too many launches side by side?): this one again, alone, one launch per body
-            l->ng_inlaunch = false;
-            l->small_disabled = true;
-            l->small_words_clean = false;
-            if ((rc = run_loops(&loops[i], 1, &k_out[i]))) return rc;
-            l->small_disabled = false;         // (alone it would have been resident: only this call falls back)
-            continue;
-        }
-        if ((rc = loop_collect(l, &k_out[i]))) return rc;
-    }
+    if ((rc = collect())) return drain(rc);
     return GNN_OK;
 }
 
@@ -2048,7 +2148,7 @@ static int readout_partial(gnn_loop *lm, int G, const int32_t *ng_indptr, const 
     const bool same = lm->ng_key == key && lm->ng_w_host.size() == (size_t)nnz &&
                       (nnz == 0 || memcmp(lm->ng_w_host.data(), ng_w, sizeof(float) * nnz) == 0);
     int rc = GNN_OK;
-    if (same && lm->ng_inlaunch && lm->ng_G == G) return GNN_OK;      // the persistent launch of this run has already computed it (gnn_small.hip)
+    if (same && gnn_loop_ng_folded(lm) && lm->ng_G == G) return GNN_OK;      // the persistent launch of this run has already computed it (gnn_small.hip)
     if (!same) {
         lm->ng_inlaunch = false;
         (void)hipFree(lm->ng_ip); (void)hipFree(lm->ng_node); (void)hipFree(lm->ng_w); (void)hipFree(lm->ng_out); (void)hipFree(lm->ng_part);
@@ -2072,7 +2172,7 @@ static int readout_partial(gnn_loop *lm, int G, const int32_t *ng_indptr, const 
 
 static int readout_combine(gnn_loop *lm, int G, float *out_graph)
 {
-    if (lm->ng_inlaunch && lm->ng_G == G && lm->world == 1) {      // folded into the persistent launch: the result is in pinned host memory
+    if (gnn_loop_ng_folded(lm) && lm->ng_G == G && lm->world == 1) {      // folded into the persistent launch: the result is in pinned host memory
         memcpy(out_graph, lm->ng_host, sizeof(float) * (size_t)G * lm->T);
         return GNN_OK;
     }

@@ -30,6 +30,7 @@ struct GnnFusedArgs {
     const int *gate;
     int *flag_out;
     int world;
+    int certify;             // 1 (split arithmetic): also raise the "robust" / "borderline" words of the certified gate (gnn_flag_raise_certified)
     int *tile_ctr;           // device-wide tile counter of this iteration (zeroed at the start of gnn_loop_run)
     int wstride;             // 1 normally; 0 (GNN_FUSED_DEBUG=1, timing experiments only) makes every K-step re-read step 0
     int stagger;             // s_sleep(127) rounds the second half of the waves waits before its first tile
@@ -50,6 +51,9 @@ struct GnnFusedArgs {
     int single_ticket;       // 1: the launch has no more tiles than waves - a wave draws ONE ticket at start (no look-ahead tile)
     // diagnostics only (GNN_FUSED_STAMPS=<file>): s_memtime stamps per wave at the phase boundaries, else nullptr
     unsigned long long *stamps;
+    // diagnostics only (GNN_POISON=1, diagnostic build): floats of the launch's dynamic LDS allocation that every workgroup fills with NaN
+    // before its first tile (a read of a never-written LDS word then shows as a NaN instead of a stale value), else 0
+    int lds_floats;
 };
 
 // control block of the persistent small-graph loop (gnn_small.hip)

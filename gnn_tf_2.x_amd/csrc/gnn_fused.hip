@@ -207,14 +207,14 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
     }
     if (m->packed_floats != p.total) {
         gnn_fused_release(m);
-        HIPCHK(hipMalloc((void **)&m->packed, p.total * sizeof(float)));
+        HIPCHK(gnn_dev_malloc((void **)&m->packed, p.total * sizeof(float)));
         m->packed_floats = p.total;
     }
     HIPCHK(hipMemcpy(m->packed, img.data(), p.total * sizeof(float), hipMemcpyHostToDevice));
     if (m->packed_split_dwords != p.s_total) {
         if (m->packed_split) (void)hipFree(m->packed_split);
         m->packed_split = nullptr;
-        HIPCHK(hipMalloc((void **)&m->packed_split, p.s_total * sizeof(uint32_t)));
+        HIPCHK(gnn_dev_malloc((void **)&m->packed_split, p.s_total * sizeof(uint32_t)));
         m->packed_split_dwords = p.s_total;
     }
     HIPCHK(hipMemcpy(m->packed_split, simg.data(), p.s_total * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -222,7 +222,7 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
         if (m->packed_split16) (void)hipFree(m->packed_split16);
         m->packed_split16 = nullptr;
         m->packed_split16_dwords = 0;
-        if (!simg16.empty()) HIPCHK(hipMalloc((void **)&m->packed_split16, simg16.size() * sizeof(uint32_t)));
+        if (!simg16.empty()) HIPCHK(gnn_dev_malloc((void **)&m->packed_split16, simg16.size() * sizeof(uint32_t)));
         m->packed_split16_dwords = simg16.size();
     }
     if (!simg16.empty()) HIPCHK(hipMemcpy(m->packed_split16, simg16.data(), simg16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -265,7 +265,7 @@ int gnn_fused_prepare(gnn_loop *l)
     if (!l->inv) {
         // (rows padded to whole 32-node tiles and zeroed: the full-tile kernel reads the label columns of a partial last tile unguarded)
         const size_t inv_floats = std::max<size_t>(1, (size_t)((g->n_rows + 31) / 32 * 32) * IW);
-        HIPCHK(hipMalloc((void **)&l->inv, inv_floats * sizeof(float)));
+        HIPCHK(gnn_dev_malloc((void **)&l->inv, inv_floats * sizeof(float)));
         HIPCHK(hipMemsetAsync(l->inv, 0, inv_floats * sizeof(float), l->stream));
     }
     if (IW == 0) return GNN_OK;
@@ -326,6 +326,7 @@ static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs
     a.gate = l->flags + (size_t)k * P * GNN_FLAG_WORDS;
     a.flag_out = l->flags + ((size_t)(k + 1) * P + l->rank) * GNN_FLAG_WORDS;
     a.world = P;
+    a.certify = split ? 1 : 0;
     a.stamps = nullptr;
     a.agg_in = l->slice_mode ? l->agg_own : nullptr;
     a.threads = 0;
@@ -355,7 +356,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     static unsigned long long *stamp_buf = nullptr;
     const size_t n_waves = n_tiles;
     if (stamp_file && k == 1) {
-        if (!stamp_buf) HIPCHK(hipMalloc((void **)&stamp_buf, n_waves * 8 * sizeof(unsigned long long)));
+        if (!stamp_buf) HIPCHK(gnn_dev_malloc((void **)&stamp_buf, n_waves * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(stamp_buf, 0, n_waves * 8 * sizeof(unsigned long long), l->stream));
         a.stamps = stamp_buf;
     }
@@ -391,6 +392,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     // launch gets none (N = 31k: 488 of 2,048 waves did all the work) - the look-ahead ticket is only drawn when every wave has a tile
     a.single_ticket = n_tiles <= (size_t)GNN_FUSED_WAVES * grid ? 1 : 0;
     const size_t lds = lds_bytes(p);
+    a.lds_floats = gnn_poison_enabled() ? (int)(lds / sizeof(float)) : 0;
     auto go = [&](const GnnFusedArgs &aa, unsigned gr) -> bool {
         if (split) {
             if (p.layers == 1) return gnn_fused_launch_s1(p.act, p.NT, p.NTL, aa, gr, lds, l->stream);
@@ -487,7 +489,7 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
         if (l->small_xs_floats < need) {
             if (l->small_xs) (void)hipFree(l->small_xs);
             l->small_xs = nullptr; l->small_xs_floats = 0;
-            HIPCHK(hipMalloc((void **)&l->small_xs, need * sizeof(float)));
+            HIPCHK(gnn_dev_malloc((void **)&l->small_xs, need * sizeof(float)));
             l->small_xs_floats = need;
         }
         c.xs = l->small_xs;
@@ -533,6 +535,7 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
             if (l->ng_host) {
                 c.ng_ip = l->ng_ip; c.ng_node = l->ng_node; c.ng_w = l->ng_w; c.ng_host = l->ng_host; c.G = l->ng_G; c.ro_word = l->max_iter + 1;
                 l->ng_inlaunch = true;                            // (cleared again by run_loops if the launch gives up)
+                l->ng_inlaunch_run = l->out_runs;                 // ... and valid for THIS run's outputs only
             }
         }
     }
@@ -547,7 +550,7 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
     static const char *small_stamp_file = getenv("GNN_SMALL_STAMPS");
     static unsigned long long *small_stamp_buf = nullptr;
     if (small_stamp_file) {
-        if (!small_stamp_buf) HIPCHK(hipMalloc((void **)&small_stamp_buf, 256 * sizeof(unsigned long long)));
+        if (!small_stamp_buf) HIPCHK(gnn_dev_malloc((void **)&small_stamp_buf, 256 * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(small_stamp_buf, 0, 256 * sizeof(unsigned long long), l->stream));
         a.stamps = small_stamp_buf;
     }
@@ -560,8 +563,12 @@ int gnn_small_run(gnn_loop *l, bool *output_done)
         s0 = (s0 + 3) / 4 * 4;                                       // instantiated: 4, 8, ..., 24 K-steps of 4
         c.KP16 = std::max((a.in_s + 3) / 4 * 4, 4 * s0);
         if (c.KP16 % 8 == 0) c.KP16 += 4;                            // rows 16 bytes apart in the banks: the B-operand column reads do not conflict
+        a.lds_floats = gnn_poison_enabled() ? (int)(gnn_small16_lds_bytes(c.KP16) / sizeof(float)) : 0;
         launched = gnn_small16_launch(p.layers, p.act, s0, a, c, grid, gnn_small16_lds_bytes(c.KP16), l->stream);
-    } else launched = gnn_small_launch(p.layers, p.act, kk_small, a, c, grid, lds, l->stream);
+    } else {
+        a.lds_floats = gnn_poison_enabled() ? (int)(lds / sizeof(float)) : 0;
+        launched = gnn_small_launch(p.layers, p.act, kk_small, a, c, grid, lds, l->stream);
+    }
     if (!launched)
         return gnn_fail(GNN_ERR_UNSUPPORTED, "no persistent-loop instantiation for %d layers, activation %d", p.layers, p.act);
     HIPCHK(hipGetLastError());

@@ -1011,8 +1011,15 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
     const float root = sqrtf(s_);
     const float nrm = shfl_f(root, (lane & 31) + 32);
     const float rhs = a.thr * nrm;
-    const int moved = (half == 0) && ((lane & 31) < nvalid) && (root > rhs);
+    const bool voter = (half == 0) && ((lane & 31) < nvalid);
+    const int moved = voter && (root > rhs);
     if (moved_out) *moved_out = __any(moved) ? 1 : 0;
+    else if (a.certify) {      // split arithmetic: certified gate
+        const float band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
+        const int robust = voter && (root > rhs + band), border = voter && (__builtin_fabsf(root - rhs) <= band);
+        const bool am = __any(moved), ar = __any(robust), ab = __any(border);
+        if (lane == 0) gnn_flag_raise_certified(a.flag_out, am, ar, ab);
+    }
     else if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
 }
 
@@ -1076,8 +1083,11 @@ __device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, flo
     d2 = d2 + shfl_f(d2, lane ^ 32);
     o2 = o2 + shfl_f(o2, lane ^ 32);
     const float root = sqrtf(d2), nrm = sqrtf(o2);
-    const int moved = root > a.thr * nrm;
-    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    {   // certified gate (gnn_common.h): both half-lanes of a node hold the same sums
+        const float rhs = a.thr * nrm, band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
+        const bool am = __any(root > rhs), ar = __any(root > rhs + band), ab = __any(__builtin_fabsf(root - rhs) <= band);
+        if (lane == 0) gnn_flag_raise_certified(a.flag_out, am, ar, ab);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float *dst = a.state_nxt + i0 * 64 + lane * 4;                           // flat element 256 u + 4 lane = row 4u + lane/16
     const float *xs = X + (lane >> 4) * KP + c_aggs + (lane & 15) * 4;
@@ -1141,8 +1151,12 @@ __device__ __forceinline__ void finish_fast64_partial(const GnnFusedArgs &a, flo
     d2 = d2 + shfl_f(d2, lane ^ 32);
     o2 = o2 + shfl_f(o2, lane ^ 32);
     const float root = sqrtf(d2), nrm = sqrtf(o2);
-    const int moved = ((lane & 31) < nvalid) && (root > a.thr * nrm);
-    if (__any(moved) && lane == 0) gnn_flag_raise(a.flag_out);
+    {   // certified gate (gnn_common.h); rows past the end of the range do not vote
+        const bool voter = (lane & 31) < nvalid;
+        const float rhs = a.thr * nrm, band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
+        const bool am = __any(voter && root > rhs), ar = __any(voter && root > rhs + band), ab = __any(voter && __builtin_fabsf(root - rhs) <= band);
+        if (lane == 0) gnn_flag_raise_certified(a.flag_out, am, ar, ab);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float *dst = a.state_nxt + i0 * 64 + lane * 4;                           // flat element 256 u + 4 lane = row 4u + lane/16
     const float *xs = X + (lane >> 4) * KP + c_aggs + (lane & 15) * 4;
@@ -1230,6 +1244,12 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // gather at once and then compute at once: HBM idles during compute, the matrix pipe during the gather).
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!gnn_gate_open(a.gate, a.world)) return;
+#ifdef GNN_DIAG      // GNN_POISON=1: NaN over the whole LDS allocation (tiles, alignment holes, look-ahead slack, staged vectors) before anything is staged
+    if (a.lds_floats) {
+        for (int t = threadIdx.x; t < a.lds_floats; t += blockDim.x) lds[t] = __builtin_nanf("");
+        __syncthreads();
+    }
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KP = a.KP, Ds = a.Ds;
     float *X = lds + (size_t)wave * 32 * KP;

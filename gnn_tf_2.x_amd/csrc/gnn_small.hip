@@ -138,6 +138,12 @@ __global__ void __launch_bounds__(64) k_small_loop(const GnnFusedArgs a0, const 
 #else
 #define SMALL_STAMP() do { } while (0)
 #endif
+#ifdef GNN_DIAG      // GNN_POISON=1: NaN over the whole LDS allocation before anything is staged (one-wave workgroup: program order is enough)
+    if (a0.lds_floats) {
+        for (int t = lane; t < a0.lds_floats; t += 64) lds[t] = __builtin_nanf("");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+#endif
     SMALL_STAMP();
     const int KP = a0.KP, Ds = a0.Ds, c_aggs = a0.c_aggs, half = lane >> 5;
     float *X = lds;

@@ -123,6 +123,10 @@ __device__ __forceinline__ void small16_layer(const float *b_base, const float (
         // another basic block - and hipcc (ROCm 7.2) then inserts no wait states between an 8-pass MFMA and the v_accvgpr_read of its
         // last destination register: with the linear activation (the read follows at once) feature 3 of every node came out stale
         // (found by test_persistent_small_graph_loop_random_shapes).  Sixteen wait states here cover the 8-pass result.
+        // Guard: `make hazard-scan` (tools/scan_mfma_hazard.py over the ISA listings of every MFMA translation unit, run by build()) fails
+        // the build if such an edge reappears.  Tying the wait to the data instead - acc[0] as an in / out operand of this statement,
+        // "+v" or "+a" - was tried in round 4 and RE-CREATES the hazard: the compiler then copies the accumulator for the operand
+        // (v_accvgpr_read / v_accvgpr_mov) as the first instruction of this block, in front of the s_nop (108 hits in the scan).
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
     }
 }
@@ -146,6 +150,12 @@ __global__ void __launch_bounds__(64) k_small16(const GnnFusedArgs a0, const Gnn
     } while (0)
 #else
 #define SMALL_STAMP() do { } while (0)
+#endif
+#ifdef GNN_DIAG      // GNN_POISON=1: NaN over the whole LDS allocation before anything is staged (one-wave workgroup: program order is enough)
+    if (a0.lds_floats) {
+        for (int t = lane; t < a0.lds_floats; t += 64) lds[t] = __builtin_nanf("");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
 #endif
     SMALL_STAMP();
     const int KP = c.KP16, Ds = a0.Ds, c_aggs = a0.c_aggs;

@@ -1657,7 +1657,7 @@ struct TrainArena {
                 return r;
             }
         Slab s{nullptr, std::max<size_t>(bytes, (size_t)32 << 20)};
-        if (hipMalloc((void **)&s.p, s.size) != hipSuccess) return nullptr;
+        if (gnn_dev_malloc((void **)&s.p, s.size) != hipSuccess) return nullptr;
         slabs.push_back(s);
         cur = slabs.size() - 1;
         off = bytes;
@@ -2415,8 +2415,8 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
             std::vector<int32_t> fill(sip.begin(), sip.end() - 1);
             for (int64_t d = 0; d < N; ++d)
                 for (int32_t e = ip[d]; e < ip[d + 1]; ++e) { const int32_t q = fill[src[e]]++; sdst[q] = (int32_t)d; sw[q] = w[e]; }
-            if (hipMalloc((void **)&sh->src_indptr, sizeof(int32_t) * (N + 1)) != hipSuccess || hipMalloc((void **)&sh->src_dst, sizeof(int32_t) * std::max<int64_t>(E, 1)) != hipSuccess ||
-                hipMalloc((void **)&sh->src_w, sizeof(float) * std::max<int64_t>(E, 1)) != hipSuccess)
+            if (gnn_dev_malloc((void **)&sh->src_indptr, sizeof(int32_t) * (N + 1)) != hipSuccess || gnn_dev_malloc((void **)&sh->src_dst, sizeof(int32_t) * std::max<int64_t>(E, 1)) != hipSuccess ||
+                gnn_dev_malloc((void **)&sh->src_w, sizeof(float) * std::max<int64_t>(E, 1)) != hipSuccess)
                 return gnn_fail(GNN_ERR_HIP, "hipMalloc of the by-source adjacency failed");
             HIPCHK(hipMemcpy(sh->src_indptr, sip.data(), sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
             if (E) { HIPCHK(hipMemcpy(sh->src_dst, sdst.data(), sizeof(int32_t) * E, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(sh->src_w, sw.data(), sizeof(float) * E, hipMemcpyHostToDevice)); }
@@ -2558,6 +2558,10 @@ static int train_forward(gnn_loop *l, const int32_t *src_indptr, const int32_t *
         HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * std::min(have, replica_floats), hipMemcpyDeviceToDevice, st));
     }
     else if (N) HIPCHK(hipMemcpyAsync(l->state[0], state, sizeof(float) * (size_t)N * Ds, hipMemcpyDeviceToDevice, st));
+    // (l->out changes here without loop_prepare: a graph readout that an earlier inference run folded into its persistent launch -
+    // ng_host - must not be handed out for these outputs)
+    l->ng_inlaunch = false;
+    ++l->out_runs;
     if (M) HIPCHK(hipMemcpyAsync(l->out, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemsetAsync(l->kfinal_dev, 0, sizeof(int), st));
     if (out_nodes_host && M) HIPCHK(hipMemcpyAsync(out_nodes_host, cx->out_nodes, sizeof(float) * (size_t)M * T, hipMemcpyDeviceToHost, st));
@@ -2764,7 +2768,7 @@ int optimizer_apply(hipStream_t st, gnn_mlp *m, const Net &net, int calls, int k
 {
     const size_t total = net.g_total;
     if (!m->opt_a) {
-        if (hipMalloc((void **)&m->opt_a, sizeof(float) * total) != hipSuccess || hipMalloc((void **)&m->opt_b, sizeof(float) * total) != hipSuccess)
+        if (gnn_dev_malloc((void **)&m->opt_a, sizeof(float) * total) != hipSuccess || gnn_dev_malloc((void **)&m->opt_b, sizeof(float) * total) != hipSuccess)
             return gnn_fail(GNN_ERR_HIP, "hipMalloc of the optimizer slots failed");
         HIPCHK(hipMemsetAsync(m->opt_a, 0, sizeof(float) * total, st));
         HIPCHK(hipMemsetAsync(m->opt_b, 0, sizeof(float) * total, st));

@@ -233,8 +233,17 @@ int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets
  *       pieces and the six leading piece products are accumulated in fp32 (error per product <= 3 * 2^-24, i.e. fp32
  *       rounding level), activations through v_exp_f32 / v_rcp_f32; results within fp32 rounding noise of 0 / 1
  *       (tests: 1e-5 against the float64 oracle, the tolerance of BASELINE.json), not bit for bit.
- * 1 and 2 fall back to 0 when the shapes are not covered.  *used (may be NULL) reports the choice. */
+ * 1 and 2 fall back to 0 when the shapes are not covered.  *used (may be NULL) reports the choice.
+ * k contract of impl 2 (reference GNN/GNN.py:202-220: `distance > threshold * norm`, reduce_any, k < max_iteration): its iteration count
+ * is the bit-exact chain's.  Every body also records whether some node moved by a margin ("robust") and whether some node's test lay
+ * within a guard band of the threshold ("borderline"; band = 1e-5 norm + 1e-3 threshold norm); a gate with a robust mover, or without
+ * a borderline node, is decided identically by both arithmetics.  When a gate of a run is neither, gnn_loop_run repeats that Loop on
+ * impl 1 before it returns, and k, state and output are THAT run's (bit-identical to the oracle).  threshold 0 with moving states never
+ * triggers it. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);
+/* Outcome of the certified gate: *last_run_repeated = 1 when the last gnn_loop_run / _run_group / _run_many of this loop was repeated on
+ * impl 1 (its results are the exact path's), *repeats_total = how often that has happened on this handle.  Either pointer may be NULL. */
+int gnn_loop_gate_info(const gnn_loop *l, int *last_run_repeated, int *repeats_total);
 /* Small graphs (every 32-node tile resident at once: <= 8,192 owned nodes, single GPU) with a net_state no wider than 32 run
  * the whole tf.while_loop of GNN/GNN.py:271 - initial state, first condition, every body with a grid barrier in between - in
  * ONE persistent launch when impl is 1 or 2 (exact f32-MFMA arithmetic in both cases, bit-identical to the oracle).  enable = 0
@@ -248,6 +257,11 @@ int gnn_loop_set_profiling(gnn_loop *l, int enable);
  * drops them, so that the next gnn_loop_run pays for them like every Loop() of the reference does (bench.py: cold figure). */
 int gnn_loop_drop_cached_aggregates(gnn_loop *l);
 int gnn_loop_get_timing(const gnn_loop *l, float *total_ms, float *avg_iter_ms, int *n_iter_timed);
+/* With profiling on: mean time on the loop's stream between the end of one body's kernel(s) and the start of the next body's, over the last
+ * run - on shards that is the per-iteration exchange (the reads of `state` at reference GNN/GNN.py:234 and the reduce_any of :218 that span
+ * all nodes: all-gather of state rows / boundary rows + flag block, or the sliced layout's pack, all-to-all, aggregation, all-to-all, unpack);
+ * a few microseconds of launch gap on one GPU.  0 unless gnn_loop_set_profiling was on. */
+int gnn_loop_get_exchange_timing(const gnn_loop *l, float *avg_between_bodies_ms);
 /* Work counters of one iteration of this loop on this rank and the timing of its last run (SURVEY.md 8b "gnn_counters_get"):
  * algorithmic bytes per iteration = E (4 Ds + 8) + 4 (n_rows + 1) + n_rows (8 Ds + 4 (2 NL + AL)) over the OWNED rows (SURVEY.md
  * 8d: fp32 values, int32 indices, no cache credit, fused iteration), FLOPs per iteration = n_rows 2 sum_l in_l out_l + 2 E Ds;

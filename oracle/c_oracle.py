@@ -29,8 +29,8 @@ def default_threads() -> int:
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, 'gnn_oracle.c')
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ('gnn_oracle.c', 'gnn_oracle_f64.c')]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'libgnn_oracle.so'], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -48,6 +48,7 @@ def lib():
         _lib.orc_expf.argtypes = [C.c_float]
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_loop.restype = C.c_int
+        _lib.orc_loop_f64.restype = C.c_int
         _lib.orc_set_threads(C.c_int(default_threads()))
     return _lib
 
@@ -150,6 +151,40 @@ def loop_node(g: dict, net_state: dict, net_output: dict, state_vect_dim: int, m
                     C.byref(m), C.c_int(n_threads))
     if rc != 0:
         raise RuntimeError(f'orc_loop failed: {rc}')
+    return float(k.value), state, out
+
+
+def loop_node_f64(g: dict, net_state: dict, net_output: dict, state_vect_dim: int, max_iteration: int, threshold: float,
+                  state0=None, n_threads: int = 0, want_out: bool = True):
+    """The float64 shadow (oracle/gnn_oracle_f64.c): same contract as loop_node, state / out returned as float64.  The arbiter for
+    rounding questions at sizes where gnn_oracle.loop_node(dtype=np.float64) is too slow."""
+    n_threads = n_threads or default_threads()
+    l = lib()
+    nodes = np.ascontiguousarray(g['nodes'], dtype=np.float32)
+    arcl = np.ascontiguousarray(np.asarray(g['arcs'], dtype=np.float32)[:, 2:])
+    n, nl, al = nodes.shape[0], nodes.shape[1], arcl.shape[1]
+    indptr = np.ascontiguousarray(g['adjT'][0], dtype=np.int32)
+    adj_src = np.ascontiguousarray(g['adjT'][1], dtype=np.int32)
+    adj_w = np.ascontiguousarray(g['adjT'][2], dtype=np.float32)
+    arc_id = np.ascontiguousarray(g['arcT'][1], dtype=np.int32)
+    arc_w = np.ascontiguousarray(g['arcT'][2], dtype=np.float32)
+    mask = np.ascontiguousarray(np.logical_and(g['set_mask'], g['output_mask']), dtype=np.uint8)
+    st = _Mlp(net_state['weights'], net_state['activations'], net_state['batch_normalization'])
+    ou = _Mlp(net_output['weights'], net_output['activations'], net_output['batch_normalization'])
+    ds = state_vect_dim if state_vect_dim else nl
+    s0 = np.ascontiguousarray(state0, dtype=np.float32) if state_vect_dim else None
+    k, m = C.c_float(0), C.c_int64(0)
+    state = np.empty((n, ds), dtype=np.float64)
+    out = np.empty((int(mask.sum()), int(ou.dims[-1])), dtype=np.float64) if want_out else None
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+    rc = l.orc_loop_f64(C.c_int64(n), _ip(indptr), _ip(adj_src), _fp(adj_w), _ip(arc_id), _fp(arc_w), _fp(nodes),
+                        C.c_int(nl), _fp(arcl), C.c_int(al), mask.ctypes.data_as(C.POINTER(C.c_uint8)),
+                        C.c_int(state_vect_dim), C.c_int(st.n), _ip(st.dims), _ip(st.acts), st.Wp, st.bp, _fp(st.bn),
+                        C.c_int(ou.n), _ip(ou.dims), _ip(ou.acts), ou.Wp, ou.bp, _fp(ou.bn), C.c_double(BN_EPS),
+                        C.c_int(max_iteration), C.c_float(threshold), _fp(s0), C.byref(k), dp(state), dp(out),
+                        C.byref(m), C.c_int(n_threads))
+    if rc != 0:
+        raise RuntimeError(f'orc_loop_f64 failed: {rc}')
     return float(k.value), state, out
 
 

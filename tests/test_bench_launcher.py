@@ -72,3 +72,19 @@ def test_mismatched_world_size_is_rejected():
     env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=4' in r.stderr
+
+
+def test_watchdog_ends_a_rank_that_hangs(tmp_path):
+    """A rank stuck in a collective must end by itself (exit 124), so that the launcher can stop the others: bench.Watchdog."""
+    script = tmp_path / 'hang.py'
+    script.write_text(textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        with bench.Watchdog(0.5, 'a collective that never returns', 3):
+            time.sleep(30)
+    """))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 124 and time.time() - t0 < 20
+    assert 'rank 3' in r.stderr and 'did not finish within' in r.stderr

@@ -64,6 +64,37 @@ def test_c3_full_size_bit_exact_vs_c_oracle(c3):
             assert ds_ <= 1e-5 * scale and do_ <= 1e-5, (ds_, do_, scale)
 
 
+def test_c3_headline_depth_parity(c3):
+    """The headline's own size AND depth (bench.py: 1,000,000 nodes, 30 bodies, threshold 0; reference loop GNN/GNN.py:271): the exact
+    path (impl 1) equals the C oracle on all 64 M state values, on the outputs and on k after 30 bodies; the default path (impl 2) stops
+    at the same k and is no further from the float64 shadow (oracle/gnn_oracle_f64.c) than 1.5 x the exact float32 chain is - with
+    random-init weights the state map is expansive, so after 30 bodies NO float32 order is within 1e-5 of float64 (measured and asserted
+    below: the oracle's own chain is 1e-5 .. 1e-4 away); what can be required of the default path at this depth is that it adds nothing
+    to the float32 noise, and that is what is asserted."""
+    e, d = c3['e'], c3['d']
+    bodies = 30
+    kc, sc, oc = corc.loop_node(c3['og'], c3['st'], c3['ou'], d, bodies, 0.0, c3['s0'])
+    k64, s64, o64 = corc.loop_node_f64(c3['og'], c3['st'], c3['ou'], d, bodies, 0.0, c3['s0'])
+    assert kc == k64 == bodies
+    res = {}
+    for impl in (1, 2):
+        loop = e.Loop(c3['graph'], c3['mst'], c3['mou'], d, bodies, 0.0)
+        assert loop.set_impl(impl) == impl
+        loop.set_state0(c3['s0'])
+        k = loop.run()
+        res[impl] = (k, loop.state(), loop.output(), loop.gate_info())
+        loop.close()
+    k1, s1, o1, _ = res[1]
+    assert k1 == kc and np.array_equal(s1, sc) and np.array_equal(o1, oc), f'impl 1: {int(np.sum(s1 != sc))} of {s1.size} state values differ after {bodies} bodies'
+    k2, s2, o2, (repeated, _) = res[2]
+    assert k2 == kc and not repeated                    # threshold 0 with moving states: every gate has a robust mover
+    e1s, e2s = float(np.max(np.abs(s1 - s64))), float(np.max(np.abs(s2 - s64)))
+    e1o, e2o = float(np.max(np.abs(o1 - o64))), float(np.max(np.abs(o2 - o64)))
+    assert e2s <= 1.5 * e1s and e2o <= 1.5 * e1o + 1e-7, (e1s, e2s, e1o, e2o)
+    assert e1s < 1e-3 and e2s < 1e-3                    # (sanity: float32 noise, not a wrong result; max |state| is about 3)
+    del s1, s2, s64, sc
+
+
 def test_c5_layer_full_size_bit_exact_vs_c_oracle(c3):
     """One layer > 0 of configs[4] at full size: the labels of the ORIGINAL graph widened by the previous layer's output
     (get_state=False, get_output=True: NL' = 5, reference LGNN.py:227-260, starter.py:78-79), relabelled on the device, then a

@@ -164,6 +164,19 @@ def test_bench_launcher_runs_all_ranks_end_to_end(gpus, exchange):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == gpus and line['steps'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
+    # the N > 1 line validates itself: 3 bodies sharded vs unsharded on every rank (bit for bit on the exact path), and it says what an
+    # iteration is made of
+    mg = line['multi_gpu']
+    assert line['parity_ok'] is True and mg['sharded_check']['ok'] is True
+    assert mg['sharded_check']['sharded_vs_unsharded_max_abs_diff'] == 0.0 and mg['sharded_check']['k_equal'] is True
+    assert mg['exchange'] in ('full', 'slice', 'slice1', 'halo') and mg['kernel_ms_per_iteration'] > 0 and mg['exchange_ms_per_iteration'] > 0
+    if mg['exchange'] == 'full':
+        assert mg['bytes_received_per_rank_per_iteration'] == (gpus - 1) * (line_nodes(line) // gpus) * 64 * 4
+
+
+def line_nodes(line):
+    import re
+    return int(re.search(r'N=(\d+) nodes', line['config']['workload']).group(1))
 
 
 def test_bench_under_torch_distributed_run():

@@ -455,6 +455,49 @@ def test_loop_training_mode_forward(cls_name):
     assert out_inf.shape == out.shape and not np.allclose(out_inf, out, atol=1e-4)
 
 
+def test_training_forward_after_a_folded_readout():
+    """An inference Loop of a small graph-based model folds the graph readout NodeGraph^T . out (reference GNN.py:331-332) into its
+    persistent launch from the second Loop on (result in pinned host memory).  A training-mode Loop on the same loop handle rewrites the
+    node outputs without going through the inference set-up: its readout must come from ITS outputs, not from the host copy the earlier
+    inference run left (round-3 advisor finding: train + evaluate(gTr) + train would have computed loss and gradients from stale outputs)."""
+    import GNN.GNN as G
+    from GNN import losses
+    from GNN.MLP import MLP
+    from GNN.graph_class import GraphObject, GraphTensor
+    rng = np.random.default_rng(17)
+    n, nl, al, d, t = 120, 3, 2, 5, 2
+    arcs = random_arcs(rng, n, 300, al)
+    nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
+    g = orc.make_graph_dict(arcs, nodes, 'average')
+    ng = np.zeros((n, 2), np.float32); ng[:70, 0] = 1 / 70; ng[70:, 1] = 1 / 50
+    g['NodeGraph'] = ng
+    ins, ls = orc.get_inout_dims('state', nl, al, t, 'g', d, [9])
+    ino, lo = orc.get_inout_dims('output', nl, al, t, 'g', d, None)
+    st, ou = make_mlp(rng, ins, ls, 'tanh', gain=0.7, bn_random=True), make_mlp(rng, ino, lo, 'tanh', out_activation='softmax', bn_random=True)
+    st['dropout'], ou['dropout'] = {}, {}
+
+    def build(net):
+        m = MLP(input_dim=net['weights'][0].shape[0], layers=[w.shape[1] for w in net['weights'][0:2 * len(net['activations']):2]],
+                activations=net['activations'], kernel_initializer='zeros', bias_initializer='zeros')
+        m.set_weights([np.asarray(w, np.float32) for w in net['weights']])
+        return m
+
+    gnn = G.GNNgraphBased(net_state=build(st), net_output=build(ou), optimizer=None, loss_function=losses.mean_squared_error, loss_arguments=None,
+                          state_vect_dim=d, max_iteration=4, threshold=0.0, addressed_problem='r')
+    go = GraphObject(arcs=arcs, nodes=nodes, targets=rng.random((2, t)), problem_based='g', aggregation_mode='average', NodeGraph=ng)
+    gt = GraphTensor.fromGraphObject(go)
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    k1, _, out1 = gnn.Loop(gt, training=False, state0=s0)          # uploads the NodeGraph
+    k2, _, out2 = gnn.Loop(gt, training=False, state0=s0)          # readout inside the persistent launch
+    assert np.array_equal(out1, out2)
+    k, state, out = gnn.Loop(gt, training=True, state0=s0)
+    ctx = tro.train_forward(g, st, ou, d, 4, 0.0, s0, [{}] * 4, {}, edge_based=False)
+    want = np.asarray(ng, np.float64).T @ ctx['out_nodes']
+    assert k == ctx['k'] == 4
+    assert np.max(np.abs(out - want)) < 2e-5, (np.max(np.abs(out - want)), np.max(np.abs(out - out2)))
+    assert not np.allclose(out, out2, atol=1e-4)                   # (batch statistics: the training-mode outputs do differ from the inference ones)
+
+
 def test_regularizers_join_the_device_gradients():
     from GNN import losses, optimizers, regularizers
     from GNN.GNN import GNNnodeBased

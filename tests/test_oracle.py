@@ -175,6 +175,21 @@ def test_loop_f32_f64_c_agree(d, gain, tol):
         assert np.max(np.abs(a - o64)) < tol
 
 
+@pytest.mark.parametrize('d,act', [(0, 'selu'), (5, 'tanh'), (7, 'sigmoid'), (4, 'elu')])
+def test_c_float64_shadow_equals_numpy_float64(d, act):
+    """oracle/gnn_oracle_f64.c (the arbiter of the full-size GPU tests, where the NumPy shadow would take minutes) against
+    gnn_oracle.loop_node(dtype=float64): same k, states and outputs to 1e-12 - masks, unsorted arcs, every activation."""
+    rng = np.random.default_rng(40 + d)
+    g, st, ou, s0 = _small_case(rng, n=180, d=d, sort=False)
+    for net in (st,):
+        net['activations'] = [act] * len(net['activations'])
+    g['set_mask'] = rng.random(180) < 0.7
+    k64, s64, o64 = orc.loop_node(g, st, ou, d, 25, 0.01, s0, np.float64)
+    kc, sc, oc = corc.loop_node_f64(g, st, ou, d, 25, 0.01, s0)
+    assert kc == k64 and sc.dtype == np.float64
+    assert np.max(np.abs(sc - s64)) < 1e-12 and np.max(np.abs(oc - o64)) < 1e-12
+
+
 def test_loop_unsorted_arcs_and_masks():
     rng = np.random.default_rng(3)
     g, st, ou, s0 = _small_case(rng, n=150, d=5, sort=False)

@@ -1,7 +1,7 @@
 """Scan hipcc's ISA listings for the pattern that bit k_small16: an MFMA as the LAST matrix instruction of a basic block,
 the block ending in a branch, and a successor block that reads one of the MFMA's destination registers within its first few instructions
 - across that edge hipcc (ROCm 7.2) did not insert the wait states an MFMA result needs before a non-MFMA read.
-Usage: python tools/scan_mfma_hazard.py file.s [...]   (listings from `hipcc -S --cuda-device-only`)
+Usage: python tools/scan_mfma_hazard.py [--fail] file.s [...]   (listings from `hipcc -S --cuda-device-only`)
 Prints the suspicious edges (kernel, line, MFMA, reading instruction, distance).  A distance of >= 12 issued instructions is taken as safe
 for the 8-pass instructions used here (16x16x4 f32, 32x32x16 bf16); the 16-pass 32x32x2 f32 needs 19."""
 import re, sys
@@ -65,10 +65,12 @@ def scan(path):
     return hits
 
 tot = 0
-for p in sys.argv[1:]:
+fail = '--fail' in sys.argv[1:]          # `make hazard-scan`: a hit fails the build
+for p in [a for a in sys.argv[1:] if a != '--fail']:
     h = scan(p)
     tot += len(h)
     print(f'{p}: {len(h)} suspicious edges')
     for k, i, t, j, u, dist in h[:40]:
         print(f'  {k}\n    line {i}: {t}\n    line {j}: {u}   ({dist} issue slots apart)')
 print('total', tot)
+if fail and tot: sys.exit(1)
