@@ -105,5 +105,8 @@ bool gnn_fused_launch_s3(int act, int nt, int ntl, const GnnFusedArgs &a, unsign
 // 16-node-tile kernel (split arithmetic, state width 64), 2 / 3 layers; nf: 16-feature tiles of the hidden layers (4 or 8)
 bool gnn_fused_launch_h2(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_h3(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+// 64-node tiles on one wave per SIMD (gnn_fused64_kernel.h; split arithmetic, state width 64, 128-wide hidden layers): gnn_fused_w{2,3}.hip
+bool gnn_fused_launch_w2(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_w3(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

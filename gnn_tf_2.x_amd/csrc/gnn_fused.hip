@@ -286,6 +286,7 @@ int gnn_fused_prepare(gnn_loop *l)
     return GNN_OK;
 }
 
+static inline int gnn_fused_dev_f64_waves() { return 4; }      // = GNN_F64_WAVES (gnn_fused64_kernel.h)
 static inline bool m_has16(const gnn_mlp *m) { return m->packed_split16 != nullptr; }
 
 // everything of the kernel arguments that does not depend on the launch geometry; split: arithmetic mode / tile layout
@@ -405,6 +406,32 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     };
     bool ok = false;
     const int64_t n_tiles64 = (g->n_rows + 31) / 32;
+    // BASELINE-size form (gnn_fused64_kernel.h): 64-node tiles on one wave per SIMD, the next tile's gather inside the current tile's matrix
+    // phase.  Split arithmetic, state width 64, 128-wide hidden layers, whole 64-row tiles only, and enough of them that every wave runs
+    // several (the first tile of a wave is not pipelined): below that k_fused's eight independent waves per CU are the better shape.
+    bool wide = false;
+    {
+        const int64_t n_tiles_w = g->n_rows / 64;
+        bool want = split && !a.agg_in && l->Ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && g->n_rows % 64 == 0 &&
+                    n_tiles_w >= (int64_t)4 * gnn_fused_dev_f64_waves() * n_cu;
+        if (l->wide_mode == 1) want = false;
+        if (l->wide_mode == 2) want = split && !a.agg_in && l->Ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && g->n_rows % 64 == 0;
+        if (want) {
+            GnnFusedArgs aw = a;
+            const int waves = gnn_fused_dev_f64_waves();
+            aw.full_tiles = 1; aw.tile_base = 0;
+            const unsigned grid_w = (unsigned)std::min<int64_t>((int64_t)n_cu, (n_tiles_w + waves - 1) / waves);
+            aw.single_ticket = n_tiles_w <= (int64_t)waves * grid_w ? 1 : 0;
+            aw.stagger = n_tiles_w >= (int64_t)4 * waves * grid_w ? stagger_rounds : 0;
+            const size_t lds_w = (size_t)waves * (64 * (size_t)(aw.KP - 64) + 4096) * sizeof(float) + 128 + (size_t)waves * 68 * sizeof(int) + (3 + 2) * 32 * 4 * sizeof(float) + 16;
+            aw.lds_floats = gnn_poison_enabled() ? (int)(lds_w / sizeof(float)) : 0;
+            if (lds_w <= 160 * 1024)
+                wide = p.layers == 2 ? gnn_fused_launch_w2(p.act, aw, grid_w, lds_w, l->stream) : gnn_fused_launch_w3(p.act, aw, grid_w, lds_w, l->stream);
+        }
+    }
+    l->wide_used = wide ? 1 : 0;
+    if (wide) ok = true;
+    else {
     // Experiment of round 3 (diagnostic build, GNN_FUSED_TILE16=1): 16-node tiles on v_mfma_f32_16x16x32_bf16, three waves per SIMD
     // (experiments/gnn_fused16_kernel.h).  Correct, and slower than this kernel at every size from 31 k to 500 k nodes:
     // every wave streams the weight image per 16 instead of 32 nodes and the vector L1 fill rate (64 B / clk / CU) becomes the bound.
@@ -433,6 +460,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         ok = go(af, (unsigned)std::min<size_t>((size_t)n_cu, (size_t)n_tiles64));
     } else
         ok = go(a, grid);
+    }
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);
 #ifdef GNN_DIAG
     if (a.stamps) {
