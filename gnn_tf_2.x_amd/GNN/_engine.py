@@ -20,7 +20,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_reset_optimizer', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loop_update_moving_statistics', 'gnn_loss_grad',
-           'gnn_counters_get', 'gnn_lgnn_run', 'gnn_loop_run_many', 'gnn_loop_set_impl', 'gnn_loop_gate_info', 'gnn_loop_set_tile_shape', 'gnn_loop_get_tile_shape', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_get_exchange_timing', 'gnn_loop_destroy', 'gnn_shard_range',
+           'gnn_counters_get', 'gnn_lgnn_run', 'gnn_loop_run_many', 'gnn_loop_set_impl', 'gnn_loop_gate_info', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_get_exchange_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
            'gnn_comm_create_loopback', 'gnn_graph_set_full_adjacency', 'gnn_loop_set_slice_exchange', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
 
@@ -561,16 +561,6 @@ class Loop:
         used = C.c_int(0)
         _check(lib().gnn_loop_set_impl(self._h, C.c_int(impl), C.byref(used)))
         return used.value
-
-    def set_tile_shape(self, mode: int) -> None:
-        """gnn_loop_set_tile_shape: 0 automatic, 1 32-node tiles (k_fused), 2 64-node tiles (k_fused64) wherever the shape allows."""
-        _check(lib().gnn_loop_set_tile_shape(self._h, C.c_int(mode)))
-
-    def tile_shape(self) -> int:
-        """rows per tile of the last run's fused iteration kernel (0: per-op path)"""
-        r = C.c_int(0)
-        _check(lib().gnn_loop_get_tile_shape(self._h, C.byref(r)))
-        return int(r.value)
 
     def gate_info(self) -> tuple:
         """gnn_loop_gate_info: (the last run was repeated on the bit-exact path because a gate of the default path was not certified, how

@@ -1,4 +1,8 @@
-// BASELINE-size form of the fused iteration kernel (gfx950): 64-node tiles on ONE wave per SIMD.  Included by gnn_fused_w{2,3}.hip.
+// EXPERIMENT of round 4, built and MEASURED SLOWER than k_fused (0.97 ms against 0.70 ms per launch at BASELINE size; phase stamps and the reason in
+// profiles/r04_fused64_stamps.txt).  Diagnostic build only (make DIAG=1, GNN_FUSED_WIDE=1); bit-identical to k_fused's impl 2
+// (tools/check_wide_tiles.py).  Kept because it is the measured answer to "64-node tiles, one wave per SIMD, the next tile's gather under the matrix phase".
+//
+// 64-node tiles on ONE wave per SIMD.  Included by experiments/gnn_fused_w{2,3}.hip.
 //
 // Same iteration as k_fused (reference GNN/GNN.py:223-242 + :202-220: CSR neighbour gather -> net_state -> convergence test), same split
 // arithmetic (three exact bf16 pieces per fp32 operand, six piece products per term, the same product order per accumulator - results are
@@ -24,7 +28,7 @@
 //   * the epilogue re-reads the old state rows from memory (L2) for the condition and transposes the new rows through the idle ring.
 // No barrier anywhere; waves never synchronise.  Tiles are handed out by the iteration's ticket counter, one tile ahead.
 #pragma once
-#include "gnn_fused_kernel.h"
+#include "../gnn_fused_kernel.h"
 
 namespace gnn_fused_dev {
 

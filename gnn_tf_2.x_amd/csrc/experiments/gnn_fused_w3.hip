@@ -1,0 +1,6 @@
+// EXPERIMENT (diagnostic build only; measured slower than k_fused, profiles/r04_fused64_stamps.txt): 64-node-tile form of the fused iteration kernel (gnn_fused64_kernel.h), 3-layer net_state (BASELINE configs[2] / [4])
+#include "gnn_fused64_kernel.h"
+bool gnn_fused_launch_w3(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st)
+{
+    return gnn_fused_dev::launch64_act<3>(act, a, grid, lds_bytes, st);
+}

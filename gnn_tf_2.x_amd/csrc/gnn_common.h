@@ -266,8 +266,6 @@ struct gnn_loop {
     bool have_state0 = false, ran = false;
     bool graph_ready_seen = false;          // this loop's stream has waited for the graph's creation-time fills
     int impl_req = 1, impl_used = 0;
-    int wide_mode = 0;                      // fused split path, tile shape: 0 auto (64-node tiles from ~262 k owned rows on), 1 never, 2 whenever the shape allows (gnn_loop_set_tile_shape)
-    int wide_used = 0;                      // the last fused iteration ran on 64-node tiles
     int32_t *ng_ip = nullptr, *ng_node = nullptr;   // cached NodeGraph^T (graph readout)
     float *ng_w = nullptr, *ng_out = nullptr, *ng_part = nullptr;   // ng_part [world, G, T]: per-rank partial readouts
     std::vector<int32_t> ng_key;

@@ -1342,20 +1342,6 @@ extern "C" int gnn_loop_set_impl(gnn_loop *l, int impl, int *used)
     return GNN_OK;
 }
 
-extern "C" int gnn_loop_set_tile_shape(gnn_loop *l, int mode)
-{
-    ARGCHK(l && mode >= 0 && mode <= 2, "mode must be 0 (automatic), 1 (32-node tiles) or 2 (64-node tiles wherever the shape allows)");
-    l->wide_mode = mode;
-    return GNN_OK;
-}
-
-extern "C" int gnn_loop_get_tile_shape(const gnn_loop *l, int *rows_per_tile)
-{
-    ARGCHK(l && rows_per_tile, "bad arguments");
-    *rows_per_tile = l->impl_used >= 1 ? (l->wide_used ? 64 : 32) : 0;
-    return GNN_OK;
-}
-
 extern "C" int gnn_loop_gate_info(const gnn_loop *l, int *last_run_repeated, int *repeats_total)
 {
     ARGCHK(l, "loop is NULL");

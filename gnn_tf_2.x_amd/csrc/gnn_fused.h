@@ -106,6 +106,7 @@ bool gnn_fused_launch_s3(int act, int nt, int ntl, const GnnFusedArgs &a, unsign
 bool gnn_fused_launch_h2(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_h3(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 // 64-node tiles on one wave per SIMD (gnn_fused64_kernel.h; split arithmetic, state width 64, 128-wide hidden layers): gnn_fused_w{2,3}.hip
+// EXPERIMENT, diagnostic build only (experiments/gnn_fused64_kernel.h): 64-node tiles on one wave per SIMD - measured slower than k_fused
 bool gnn_fused_launch_w2(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_w3(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

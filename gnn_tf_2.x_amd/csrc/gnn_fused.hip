@@ -286,7 +286,6 @@ int gnn_fused_prepare(gnn_loop *l)
     return GNN_OK;
 }
 
-static inline int gnn_fused_dev_f64_waves() { return 4; }      // = GNN_F64_WAVES (gnn_fused64_kernel.h)
 static inline bool m_has16(const gnn_mlp *m) { return m->packed_split16 != nullptr; }
 
 // everything of the kernel arguments that does not depend on the launch geometry; split: arithmetic mode / tile layout
@@ -406,19 +405,19 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     };
     bool ok = false;
     const int64_t n_tiles64 = (g->n_rows + 31) / 32;
-    // BASELINE-size form (gnn_fused64_kernel.h): 64-node tiles on one wave per SIMD, the next tile's gather inside the current tile's matrix
-    // phase.  Split arithmetic, state width 64, 128-wide hidden layers, whole 64-row tiles only, and enough of them that every wave runs
-    // several (the first tile of a wave is not pipelined): below that k_fused's eight independent waves per CU are the better shape.
+    // EXPERIMENT of round 4 (diagnostic build, GNN_FUSED_WIDE=1): 64-node tiles on one wave per SIMD, every weight fragment feeding two 32-node
+    // halves, the next tile's gather inside the current tile's matrix phase through an LDS-DMA ring (experiments/gnn_fused64_kernel.h).
+    // Bit-identical to this kernel and slower: 0.97 ms against 0.70 ms per launch at BASELINE size (profiles/r04_fused64_stamps.txt) -
+    // vector-memory results return in order, so the weight fragments requested behind a gather batch wait for its HBM-latency rows.
     bool wide = false;
+#ifdef GNN_DIAG
     {
+        static const int wide_env = getenv("GNN_FUSED_WIDE") ? atoi(getenv("GNN_FUSED_WIDE")) : 0;
         const int64_t n_tiles_w = g->n_rows / 64;
-        bool want = split && !a.agg_in && l->Ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && g->n_rows % 64 == 0 &&
-                    n_tiles_w >= (int64_t)4 * gnn_fused_dev_f64_waves() * n_cu;
-        if (l->wide_mode == 1) want = false;
-        if (l->wide_mode == 2) want = split && !a.agg_in && l->Ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && g->n_rows % 64 == 0;
+        const bool want = wide_env && split && !a.agg_in && l->Ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && g->n_rows % 64 == 0 && n_tiles_w >= 1;
         if (want) {
             GnnFusedArgs aw = a;
-            const int waves = gnn_fused_dev_f64_waves();
+            const int waves = 4;
             aw.full_tiles = 1; aw.tile_base = 0;
             const unsigned grid_w = (unsigned)std::min<int64_t>((int64_t)n_cu, (n_tiles_w + waves - 1) / waves);
             aw.single_ticket = n_tiles_w <= (int64_t)waves * grid_w ? 1 : 0;
@@ -429,7 +428,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
                 wide = p.layers == 2 ? gnn_fused_launch_w2(p.act, aw, grid_w, lds_w, l->stream) : gnn_fused_launch_w3(p.act, aw, grid_w, lds_w, l->stream);
         }
     }
-    l->wide_used = wide ? 1 : 0;
+#endif
     if (wide) ok = true;
     else {
     // Experiment of round 3 (diagnostic build, GNN_FUSED_TILE16=1): 16-node tiles on v_mfma_f32_16x16x32_bf16, three waves per SIMD

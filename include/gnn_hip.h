@@ -241,14 +241,6 @@ int gnn_loss_grad(int loss_kind, int64_t n_rows, int n_out, const float *targets
  * impl 1 before it returns, and k, state and output are THAT run's (bit-identical to the oracle).  threshold 0 with moving states never
  * triggers it. */
 int gnn_loop_set_impl(gnn_loop *l, int impl, int *used);
-/* Tile shape of the fused iteration kernel on the split path (impl 2).  Two forms of the same arithmetic exist (bit-identical results):
- * 32-node tiles, eight independent waves per CU (k_fused: every size, every covered shape), and 64-node tiles on one wave per SIMD with
- * the next tile's gather inside the current tile's matrix phase (k_fused64: state width 64, two or three layers with 65 .. 128-wide hidden
- * layers, selu / tanh, a row count that is a multiple of 64, single GPU or node-range shards with the row all-gather).  mode 0 (default):
- * the 64-node form from 262,144 owned rows on (every wave then runs four tiles or more); 1: never; 2: wherever the shape allows.
- * gnn_loop_get_tile_shape: rows per tile of the last run's iteration kernel (0: per-op path). */
-int gnn_loop_set_tile_shape(gnn_loop *l, int mode);
-int gnn_loop_get_tile_shape(const gnn_loop *l, int *rows_per_tile);
 /* Outcome of the certified gate: *last_run_repeated = 1 when the last gnn_loop_run / _run_group / _run_many of this loop was repeated on
  * impl 1 (its results are the exact path's), *repeats_total = how often that has happened on this handle.  Either pointer may be NULL. */
 int gnn_loop_gate_info(const gnn_loop *l, int *last_run_repeated, int *repeats_total);
