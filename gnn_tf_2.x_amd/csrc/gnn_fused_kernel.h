@@ -394,6 +394,12 @@ __device__ __forceinline__ v4i bload4i(__amdgpu_buffer_rsrc_t r, int voff, int s
 struct WStream {
     int soff, n;
     __device__ __forceinline__ WStream(int start) : soff(start), n(0) {}
+    // (timing experiment of the diagnostic build: the position moves on, nothing is requested)
+    __device__ __forceinline__ void skip()
+    {
+        if (n == 4) { asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(soff) : : "scc"); n = 0; }
+        ++n;
+    }
     __device__ __forceinline__ v4i next(__amdgpu_buffer_rsrc_t r, int voff)
     {
         // (s_add_u32 writes SCC: without the clobber the compiler kept a loop's s_cmp result live across this statement and the loop of
@@ -526,9 +532,11 @@ __device__ __forceinline__ void layer0_split(const float *xr, __amdgpu_buffer_rs
 // an MFMA runs while the matrix pipe executes it): while the 6 NO MFMAs of chunk c are issued, the 8 elements of chunk
 // c + 2 get bias + activation (E) and the elements of chunk c + 1 are cut into bf16 pieces (S), one task per few MFMAs.
 // Units of (chunk, pair of output tiles), fully unrolled, weights requested DEPTH units ahead.
-template <int NI, int NO, int ACT>
+// LDSW (diagnostic build, timing experiment of round 4, results meaningless): the weight fragments of the first LDSW chunks are read from LDS
+// (whatever the wave's tile holds) instead of requested from memory - what would LDS-resident weights for part of a layer buy?
+template <int NI, int NO, int ACT, int LDSW = 0>
 __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const float *bias_lds, int half, f32x16 (&acc)[NO],
-                                                      __amdgpu_buffer_rsrc_t wrs, int voff, int soff)
+                                                      __amdgpu_buffer_rsrc_t wrs, int voff, int soff, const float *lds_junk = nullptr)
 {
     constexpr int TPU = NO >= 2 ? 2 : 1, UPC = NO / TPU, CH = 2 * NI, U = CH * UPC;
     constexpr int DEPTH = (NI + NO >= 8) ? GNN_SPLIT_DEPTH44 : 3;       // 24 VGPRs per unit in flight next to 16 (NI + NO) of activations
@@ -539,8 +547,12 @@ __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const f
     WStream ws(soff);                                   // units are requested in ascending order = image order
 #define GNN_S1_LOAD(UU)                                                                             \
     _Pragma("unroll") for (int t = 0; t < TPU; ++t)                                                 \
-        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                            \
-            w[UU][t][pc] = ws.next(wrs, voff);
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                          \
+            if (LDSW > 0 && (UU) / UPC < LDSW) {                                                    \
+                ws.skip();                                                                          \
+                w[UU][t][pc] = *reinterpret_cast<const v4i *>(lds_junk + ((((UU) * TPU + t) * 3 + pc) & 3) * 256 + (voff >> 2));   \
+            } else w[UU][t][pc] = ws.next(wrs, voff);                                               \
+        }
     // (the previous layer's accumulators already contain its bias: bias_tile)
 #define GNN_S1_H(C, I) hin[(C) >> 1][8 * ((C) & 1) + (I)]
     // SELU between dense layers, folded (gnn_fused_pack scales the split image to match): the accumulator holds v' = log2(e) v, the
@@ -1359,8 +1371,18 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
                 layer_split_from_regs<NT, NTL, ACT>(h1, ep, half, out, wrs, wv, a.ws_off[1]);
             } else {
                 f32x16 h2[NT];
+#ifdef GNN_DIAG     // timing experiment (variant bit 5): 6 of the 8 chunks of the 128 -> 128 layer, or (bit 6) also the whole last layer, fed from LDS
+                if constexpr (FULL && !GIVEN && NT == 4 && NTL == 2) {
+                    if (a.variant & 32) layer_split_from_regs<NT, NT, ACT, 6>(h1, hb + 32 * NT, half, h2, wrs, wv, a.ws_off[1], X);
+                    else layer_split_from_regs<NT, NT, ACT>(h1, hb + 32 * NT, half, h2, wrs, wv, a.ws_off[1]);
+                    if (a.variant & 64) layer_split_from_regs<NT, NTL, ACT, 8>(h2, ep, half, out, wrs, wv, a.ws_off[2], X);
+                    else layer_split_from_regs<NT, NTL, ACT>(h2, ep, half, out, wrs, wv, a.ws_off[2]);
+                } else
+#endif
+                {
                 layer_split_from_regs<NT, NT, ACT>(h1, hb + 32 * NT, half, h2, wrs, wv, a.ws_off[1]);
                 layer_split_from_regs<NT, NTL, ACT>(h2, ep, half, out, wrs, wv, a.ws_off[2]);
+                }
             }
         }
     } else if constexpr (LAYERS == 1) {
