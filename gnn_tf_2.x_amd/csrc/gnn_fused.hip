@@ -34,8 +34,11 @@ struct FusedPlan {
 };
 
 constexpr int GNN_FUSED_VARIANT_DEFAULT = 1;      // bit 0: raised wave priority during the gather (measured: -1 %)
-constexpr int GNN_FUSED_SPREAD_DEFAULT = 20;      // start-up spread: every wave waits 0 .. 20 x 8k cycles before its first tile (-3 %)
-constexpr int GNN_FUSED_SPREAD_SMALL_DEFAULT = 12;   // the same spread for grids with one to four tiles per wave
+// start-up spread: every wave waits 0 .. n x 8k cycles before its first tile.  Round 2 / 3 (two tickets per wave drawn at kernel start, which
+// already spread the waves by up to 46 us): 20 rounds, 12 for grids with one to four tiles per wave.  Round 4 (static first two rounds of
+// tiles, no atomics at start; profiles/r04_midsize.txt): 8 and 6.
+constexpr int GNN_FUSED_SPREAD_DEFAULT = 8;
+constexpr int GNN_FUSED_SPREAD_SMALL_DEFAULT = 6;
 constexpr int S_SLACK = 2;      // zero chunks after the layer-0 block of the split image (layer0_split looks two chunks ahead)
 
 int round_tiles(int width) { return width <= 32 ? 1 : (width <= 64 ? 2 : 4); }
@@ -378,8 +381,8 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     static const int stagger_env = getenv("GNN_FUSED_STAGGER") ? atoi(getenv("GNN_FUSED_STAGGER")) : GNN_FUSED_SPREAD_DEFAULT;   // tuning experiments
     stagger_rounds = stagger_env;
 #endif
-    // start-up spread (k_fused): the full amount when every wave has four or more tiles; 12 rounds between one and four tiles per wave
-    // (round 3, tools/bench_midsize.py: N = 125 k 0.154 -> 0.138 ms, 250 k 0.227 -> 0.206 ms per iteration); none when no wave has a second tile
+    // start-up spread (k_fused): the full amount when every wave has four or more tiles; the small one between one and four tiles per wave
+    // (tools/bench_midsize.py, profiles/r04_midsize.txt); none when no wave has a second tile
     a.stagger = n_tiles >= (size_t)4 * GNN_FUSED_WAVES * grid ? stagger_rounds : (n_tiles > (size_t)GNN_FUSED_WAVES * grid ? GNN_FUSED_SPREAD_SMALL_DEFAULT : 0);
 #ifdef GNN_DIAG      // experiment: small grids (1 - 4 tiles per wave) with the two-cluster offset (variant bit 2): waves 4-7 start GNN_FUSED_STAGGER_SMALL x 8k cycles late
     static const int stagger_small = getenv("GNN_FUSED_STAGGER_SMALL") ? atoi(getenv("GNN_FUSED_STAGGER_SMALL")) : 0;

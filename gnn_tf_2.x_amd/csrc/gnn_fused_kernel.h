@@ -1287,18 +1287,16 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
         else rounds = (int)((((unsigned)blockIdx.x * GNN_FUSED_WAVES + (unsigned)wave) * 0x9E3779B1u) >> 16) % (unsigned)(a.stagger + 1);
         for (int i = 0; i < rounds; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    // Tiles are handed out by a device-wide ticket counter; a wave knows its next tile one tile ahead (ticket drawn at the end
-    // of the previous tile's dense layers), early enough to have that tile's row pointers and first gather ids requested.
-    // (Serving the tickets heaviest-tile-first was measured: 1 % slower on the BASELINE graph.)
-#ifdef GNN_DIAG     // diagnostic build: variant bit 3 makes ONE wave of the launch start late (wave 0 of workgroup 0, about 250 us) - with bit 4
-    // (the wasted look-ahead draw of single-ticket launches as it was before the fix, below) that wave then finds its tile's number gone
-    if ((a.variant & 8) && blockIdx.x == 0 && wave == 0)
-        for (int i = 0; i < 64; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
-    int tile = 0, next_tile = 0;
-    if (lane == 0) { tile = atomicAdd(a.tile_ctr, 1); next_tile = a.single_ticket ? 0x3fffffff : atomicAdd(a.tile_ctr, 1); }
-    tile = __builtin_amdgcn_readfirstlane(tile) + a.tile_base;
-    next_tile = __builtin_amdgcn_readfirstlane(next_tile) + a.tile_base;
+    // Tiles: the first TWO rounds are assigned statically - wave w of the launch (wave-major over the workgroups, so that a partial round
+    // spreads over all CUs) takes tiles w and w + W, W = waves of the launch - and only from the third round on does a wave draw tickets
+    // from the iteration's counter, one tile ahead (at the end of the previous tile's dense layers), early enough to have that tile's row
+    // pointers and first gather ids requested.  (Until round 4 every wave drew its first two tickets at kernel start: 4,096 atomic adds on
+    // ONE word, which the memory side serves at about 88 per microsecond - up to 46 us before the last wave knew its first tile, a third
+    // of an iteration at 125 k nodes.  Serving the tickets heaviest-tile-first was measured in round 2: 1 % slower on the BASELINE graph.)
+    const int W_launch = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int w_launch = wave * (int)gridDim.x + (int)blockIdx.x;
+    const bool third_round = (int64_t)2 * W_launch * 32 < a.n_rows;          // wave-uniform: tickets are only drawn when tiles beyond 2 W exist
+    int tile = w_launch + a.tile_base, next_tile = w_launch + W_launch + a.tile_base;
     int ip_cur = tile_rowptr_clamp(a, tile, lane, tile_rowptr_request(a, tile, lane));
     int src_cur = 0;
     float w_cur = 0.0f;
@@ -1411,15 +1409,11 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     // Requests for the tile after next (ticket) and for the next tile (ids / weights of its first gather batch): issued HERE,
     // behind the last weight loads, because vector-memory results return in issue order - in front of the dense layers these
     // HBM-latency loads would hold up every weight wait - and the epilogue / norm / stores below cover their latency.
-    // (single_ticket: NO draw here.  A wave of such a launch never runs a second tile, so the ticket would be thrown away - and if a
-    // wave that starts late had not drawn its first ticket yet, the discarded number could be a real tile that nobody then runs.)
+    // (no draw when the launch has no third round: two static tiles per wave cover it)
     int next2_tile = 0x3fffffff;
-#ifdef GNN_DIAG
-    if (lane == 0 && (!a0.single_ticket || (a0.variant & 16))) next2_tile = atomicAdd(a0.tile_ctr, 1);
-    if (a0.single_ticket) next2_tile = 0x3fffffff;
-#else
-    if (lane == 0 && !a0.single_ticket) next2_tile = atomicAdd(a0.tile_ctr, 1);
-#endif
+    if (third_round) {
+        if (lane == 0) next2_tile = atomicAdd(a0.tile_ctr, 1) + 2 * W_launch;
+    }
     const int ip_next = tile_rowptr_clamp(a, next_tile, lane, ip_next_raw);
     int src_next = 0;
     float w_next = 0.0f;
