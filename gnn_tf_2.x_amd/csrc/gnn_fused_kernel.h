@@ -1266,6 +1266,17 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     const int KP = a.KP, Ds = a.Ds;
     float *X = lds + (size_t)wave * 32 * KP;
     const int c_aggs = a.c_aggs;                      // column of the aggregated state block (Ds + NLc + alignment hole)
+    // Tiles: the first TWO rounds are assigned statically - wave w of the launch (wave-major over the workgroups, so that a partial round
+    // spreads over all CUs) takes tiles w and w + W, W = waves of the launch - and only from the third round on does a wave draw tickets
+    // from the iteration's counter, one tile ahead (at the end of the previous tile's dense layers), early enough to have that tile's row
+    // pointers and first gather ids requested.  (Until round 4 every wave drew its first two tickets at kernel start: 4,096 atomic adds on
+    // ONE word, which the memory side serves at about 88 per microsecond - up to 46 us before the last wave knew its first tile, a third
+    // of an iteration at 125 k nodes.  Serving the tickets heaviest-tile-first was measured in round 2: 1 % slower on the BASELINE graph.)
+    const int W_launch = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int w_launch = wave * (int)gridDim.x + (int)blockIdx.x;
+    const bool third_round = (int64_t)2 * W_launch * 32 < a.n_rows;          // wave-uniform: tickets are only drawn when tiles beyond 2 W exist
+    int tile = w_launch + a.tile_base, next_tile = w_launch + W_launch + a.tile_base;
+    const int ip_first_raw = tile_rowptr_request(a, tile, lane);      // on its way while the workgroup stages its vectors below
     // last-layer bias and BatchNormalization scale / shift: staged once per workgroup behind the row-pointer slots
     float *ep = lds + (size_t)GNN_FUSED_WAVES * 32 * KP + 32 + GNN_FUSED_WAVES * 36;
     for (int t = threadIdx.x; t < 3 * 32 * NTL; t += blockDim.x) {
@@ -1287,17 +1298,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
         else rounds = (int)((((unsigned)blockIdx.x * GNN_FUSED_WAVES + (unsigned)wave) * 0x9E3779B1u) >> 16) % (unsigned)(a.stagger + 1);
         for (int i = 0; i < rounds; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    // Tiles: the first TWO rounds are assigned statically - wave w of the launch (wave-major over the workgroups, so that a partial round
-    // spreads over all CUs) takes tiles w and w + W, W = waves of the launch - and only from the third round on does a wave draw tickets
-    // from the iteration's counter, one tile ahead (at the end of the previous tile's dense layers), early enough to have that tile's row
-    // pointers and first gather ids requested.  (Until round 4 every wave drew its first two tickets at kernel start: 4,096 atomic adds on
-    // ONE word, which the memory side serves at about 88 per microsecond - up to 46 us before the last wave knew its first tile, a third
-    // of an iteration at 125 k nodes.  Serving the tickets heaviest-tile-first was measured in round 2: 1 % slower on the BASELINE graph.)
-    const int W_launch = (int)gridDim.x * (int)(blockDim.x >> 6);
-    const int w_launch = wave * (int)gridDim.x + (int)blockIdx.x;
-    const bool third_round = (int64_t)2 * W_launch * 32 < a.n_rows;          // wave-uniform: tickets are only drawn when tiles beyond 2 W exist
-    int tile = w_launch + a.tile_base, next_tile = w_launch + W_launch + a.tile_base;
-    int ip_cur = tile_rowptr_clamp(a, tile, lane, tile_rowptr_request(a, tile, lane));
+    int ip_cur = tile_rowptr_clamp(a, tile, lane, ip_first_raw);
     int src_cur = 0;
     float w_cur = 0.0f;
     if (FULL || Ds == 64) tile_first_ids(a, ip_cur, lane, src_cur, w_cur);
