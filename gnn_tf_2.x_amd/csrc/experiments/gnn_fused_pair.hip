@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
             if (a.bn_scale) tile_epilogue<ACT, true, true, true, true>(out[jt], ep, ep + 32 * NTL, ep + 64 * NTL, jt, half);
             else tile_epilogue<ACT, false, true, true, true>(out[jt], ep, nullptr, nullptr, jt, half);
         }
-        if (nvalid == 32) finish_fast64_aligned(a, X, out, i0, lane, KP, c_aggs);
+        if (nvalid == 32) { GnnFlagPeek pk = {0, 0, 0}; if (lane == 0) pk = gnn_flag_peek(a.flag_out); finish_fast64_aligned(a, X, out, i0, lane, KP, c_aggs, pk); }
         else finish_fast64_partial(a, X, out, i0, lane, KP, c_aggs, nvalid);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (lane == 0) lds_flag_store(full + b, 0);          // every LDS read of the buffer has completed (lgkmcnt 0); the row stores fly on

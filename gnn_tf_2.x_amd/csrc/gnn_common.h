@@ -122,6 +122,26 @@ __device__ __forceinline__ void gnn_flag_raise(int *flag_rank_base)
 // tests/test_gpu_parity.py), and it only matters for the body at which a loop stops - where, by definition, nothing moves robustly.
 #define GNN_BAND_ABS 1e-5f
 #define GNN_BAND_REL 1e-3f
+// The same in two steps, for the hot path: peek() requests the three words early (the flags only ever go from 0 to 1, so a value read
+// early is at worst a reason for a redundant OR), raise() decides at the end of the tile without waiting for memory.
+struct GnnFlagPeek { int c0, c1, c2; };
+__device__ __forceinline__ GnnFlagPeek gnn_flag_peek(int *flag_rank_base)
+{
+    int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;
+    GnnFlagPeek p;
+    p.c0 = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.c1 = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.c2 = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return p;
+}
+__device__ __forceinline__ void gnn_flag_raise_peeked(int *flag_rank_base, const GnnFlagPeek &p, bool moved, bool robust, bool border)
+{
+    int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;
+    if (moved && p.c0 == 0) atomicOr(w, 1);
+    if (robust && p.c1 == 0) atomicOr(w + 1, 1);
+    if (border && p.c2 == 0) atomicOr(w + 2, 1);
+}
+
 __device__ __forceinline__ void gnn_flag_raise_certified(int *flag_rank_base, bool moved, bool robust, bool border)
 {
     int *w = flag_rank_base + (blockIdx.x & (GNN_FLAG_SLOTS - 1)) * GNN_FLAG_STRIDE;

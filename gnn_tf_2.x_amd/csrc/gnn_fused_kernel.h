@@ -1075,7 +1075,9 @@ __device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float 
 // its 32 features of (new - old)^2 and old^2 (old state: aligned 16-byte reads of the tile), the two halves of a node are added
 // across lanes l / l + 32.  The summation order differs from the oracle's ascending-feature chain; on this path the state
 // itself already differs from the oracle in the last bits, so that is within the same tolerance (k is compared in the tests).
-__device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, float *X, f32x16 (&out)[2], int64_t i0, int lane, int KP, int c_aggs)
+// peek: the gate words of this wave's slot, requested by lane 0 behind the last weight loads (gnn_flag_peek)
+__device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, float *X, f32x16 (&out)[2], int64_t i0, int lane, int KP, int c_aggs,
+                                                      const GnnFlagPeek &peek)
 {
     const int half = lane >> 5;
     float *xrow = X + (lane & 31) * KP;
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, flo
     {   // certified gate (gnn_common.h): both half-lanes of a node hold the same sums
         const float rhs = a.thr * nrm, band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
         const bool am = __any(root > rhs), ar = __any(root > rhs + band), ab = __any(__builtin_fabsf(root - rhs) <= band);
-        if (lane == 0) gnn_flag_raise_certified(a.flag_out, am, ar, ab);
+        if (lane == 0) gnn_flag_raise_peeked(a.flag_out, peek, am, ar, ab);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float *dst = a.state_nxt + i0 * 64 + lane * 4;                           // flat element 256 u + 4 lane = row 4u + lane/16
@@ -1419,6 +1421,8 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     int src_next = 0;
     float w_next = 0.0f;
     if (FULL || Ds == 64) tile_first_ids(a, ip_next, lane, src_next, w_next);
+    GnnFlagPeek peek = {0, 0, 0};                             // the gate words of this wave's slot: on their way across the epilogue arithmetic
+    if (SPLIT && NTL == 2 && lane == 0) peek = gnn_flag_peek(a.flag_out);
     bool finished = false;
     if constexpr (SPLIT && NTL == 2) {
         if (fast64) {                                         // registers -> norms, LDS (16-byte pieces), row stores
@@ -1428,7 +1432,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
                 else tile_epilogue<ACT, false, true, true, true>(out[jt], ep, nullptr, nullptr, jt, half);
             }
             GNN_STAMP(6);
-            if (nvalid == 32) finish_fast64_aligned(a, X, out, i0, lane, KP, c_aggs);
+            if (nvalid == 32) finish_fast64_aligned(a, X, out, i0, lane, KP, c_aggs, peek);
             else finish_fast64_partial(a, X, out, i0, lane, KP, c_aggs, nvalid);       // (full-tile kernel on the range's last, partial tile)
             finished = true;
         }
