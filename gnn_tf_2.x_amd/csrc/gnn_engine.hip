@@ -363,6 +363,7 @@ __global__ void k_finalize(const int *flags, int world, int max_iter, int *kfina
     for (int k = 1 + lane; k <= last; k += 64) {
         const int *gate = flags + (size_t)k * world * GNN_FLAG_WORDS;
         int robust = 0, border = 0;
+#pragma unroll 16      // (independent loads: sixteen slots' words in flight per lane instead of one dependent round trip per slot)
         for (int p = 0; p < world * GNN_FLAG_SLOTS; ++p) { robust |= gate[p * GNN_FLAG_STRIDE + 1]; border |= gate[p * GNN_FLAG_STRIDE + 2]; }
         amb |= (!robust && border) ? 1 : 0;
     }
