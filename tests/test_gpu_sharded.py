@@ -287,6 +287,37 @@ def test_sharded_edge_based_readout(world):
     assert kw == k1 and np.array_equal(sw, s1) and np.array_equal(ow, o1)
 
 
+@pytest.mark.parametrize('world,halo', [(2, False), (3, True)])
+def test_sharded_default_path_certified_gate(world, halo):
+    """The exact-k contract of the default arithmetic on shards (reference GNN/GNN.py:202-220: the reduce_any spans all nodes): a threshold
+    placed ON the largest distance / norm ratio of a body leaves that body's gate without a robust mover and with a borderline node on
+    SOME rank; every rank reads the same exchanged flag words (moved / robust / borderline), so all ranks repeat the Loop on the bit-exact
+    path together and return the oracle's k, states and outputs bit for bit."""
+    e = _engine()
+    n, d = 1500, 64
+    g, st, ou, s0 = _case(77, n, d, hidden=(128, 128), act='tanh', gain=0.5)
+    _, s3, _ = corc.loop_node(g, st, ou, d, 3, 0.0, s0)
+    _, s4, _ = corc.loop_node(g, st, ou, d, 4, 0.0, s0)
+    dist = np.zeros(n, np.float32); nrm = np.zeros(n, np.float32)
+    for c in range(d):
+        df = s4[:, c] - s3[:, c]
+        dist = dist + df * df
+        nrm = nrm + s3[:, c] * s3[:, c]
+    thr = float(np.max(np.sqrt(dist) / np.sqrt(nrm)))
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 12, thr, s0)
+    comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 12, thr, s0, world, 2, halo=halo)
+    k = e.Loop.run_group(loops)
+    assert k == kc
+    assert all(lp.gate_info()[0] for lp in loops)                   # every rank's run was the repeat on impl 1
+    state, out = _collect(loops, ranges, None)
+    assert np.array_equal(state, sc) and np.array_equal(out, oc)
+    k2 = e.Loop.run_group(loops)                                     # and the group keeps working on the default path afterwards
+    assert k2 == kc
+    for lp in loops: lp.close()
+    for gr in graphs: gr.close()
+    for c_ in comms: c_.close()
+
+
 def test_loopback_group_errors():
     e = _engine()
     g, st, ou, s0 = _case(3, 200, 4)
