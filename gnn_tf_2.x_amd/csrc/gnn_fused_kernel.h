@@ -374,6 +374,9 @@ __device__ __forceinline__ void layer_from_regs(f32x16 (&hin)[NI], const float *
 //   hidden, chunk c = 2 ti + q:        k(h, i) = 32 ti + (r & 3) + 8 (r >> 2) + 4 h,  r = 8 q + i   (accumulator register r)
 // gnn_fused.hip packs the weight pieces in the same order: [chunk][out tile][piece][lane][8 bf16].
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef GNN_S1_GROUP
+#define GNN_S1_GROUP 1
+#endif
 #ifndef GNN_SPLIT_DEPTH44
 #define GNN_SPLIT_DEPTH44 1   // measured: depth 2 spills ~40 VGPRs and is slower
 #endif
@@ -593,17 +596,24 @@ __device__ __forceinline__ void layer_split_from_regs(f32x16 (&hin)[NI], const f
                     // the first MFMA of an accumulator takes the layer's bias as C (no zeroed register tile, no bias add later)
                     acc[up * TPU + t] = mfma_bf16(w[u][t][PA[term]], v4i{bq[0], bq[1], bq[2], bq[3]},
                                                   (c == 0 && term == 0) ? bias_tile(bias_lds, up * TPU + t, half) : acc[up * TPU + t]);
-                    // VALU tasks due after MFMA number m of the chunk: [(m - 1) NTASK / NM, m NTASK / NM)
+                    // VALU tasks due after MFMA number m of the chunk: [(m - 1) NTASK / NM, m NTASK / NM).  GNN_S1_GROUP (experiment of round 4,
+                    // default 1): the tasks of G consecutive MFMAs are issued together behind the last of them, in one scheduling region
+                    // (independent dependency chains side by side instead of one chain per gap).  Measured on one box, shipped configuration:
+                    // G = 1 / 2 / 4: 0.685 / 0.689 / 0.684 ms per launch at BASELINE size, 0.182 / 0.182 / 0.184 ms at 250 k nodes - no effect.
                     const int m = (up * 6 + term) * TPU + t + 1;
-                    const int k0 = (m - 1) * NTASK / NM, k1 = m * NTASK / NM;
+                    constexpr int G = GNN_S1_GROUP;
+                    if (m % G == 0 || m == NM) {
+                        const int m0 = m % G == 0 ? m - G : m - m % G;
+                        const int k0 = m0 * NTASK / NM, k1 = m * NTASK / NM;
 #pragma unroll
-                    for (int k = 0; k < NTASK; ++k) {
-                        if (k >= k0 && k < k1) {
-                            if (k < 8) { if (c + 2 < CH) { GNN_S1_E(c + 2, k) } }
-                            else { if (c + 1 < CH) { GNN_S1_S(c + 1, k - 8, bp[(c + 1) & 1]) } }
+                        for (int k = 0; k < NTASK; ++k) {
+                            if (k >= k0 && k < k1) {
+                                if (k < 8) { if (c + 2 < CH) { GNN_S1_E(c + 2, k) } }
+                                else { if (c + 1 < CH) { GNN_S1_S(c + 1, k - 8, bp[(c + 1) & 1]) } }
+                            }
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
