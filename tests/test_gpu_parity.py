@@ -822,6 +822,30 @@ def test_run_many_runs_small_loops_side_by_side():
     for lp in loops: lp.close()
 
 
+def test_run_many_limits_what_it_queues_side_by_side():
+    """gnn_loop_run_many queues persistent launches side by side only while their workgroups sum to at most three per CU (a grid barrier
+    needs every workgroup of every launch in flight resident); past that it collects the queued ones before it queues the next.  Thirty
+    MUTAG-sized batches (about 1,100 workgroups by the call's own bound, more than 3 x 256) in one call: every loop's k, state and outputs
+    as if run alone, on two calls in a row, and none of them fell back to one launch per body (the barrier never had to give up)."""
+    e = _engine()
+    rng = np.random.default_rng(78)
+    loops, want = [], []
+    for i in range(30):
+        n = int(rng.integers(540, 640))
+        g, st, ou, s0 = _case(rng, n=n, d=0, nl=14, al=3, hidden=(32, 32), act='selu')
+        lp = e.Loop(_device_graph(g), e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), 0, 20, 0.01)
+        lp.set_impl(1)
+        assert lp.set_persistent(True)
+        loops.append(lp)
+        want.append(corc.loop_node(g, st, ou, 0, 20, 0.01, None))
+    for _ in range(2):
+        ks = e.Loop.run_many(loops)
+        for lp, k, (kc, sc, oc) in zip(loops, ks, want):
+            assert k == kc and np.array_equal(lp.state(), sc) and np.array_equal(lp.output(), oc)
+    assert all(lp.set_persistent(True) for lp in loops)      # still on the persistent path: no launch gave up
+    for lp in loops: lp.close()
+
+
 def test_lgnn_run_in_one_call_and_work_counters():
     """gnn_lgnn_run = LGNN.Loop (reference LGNN.py:263-290) of a whole stack through ONE C-ABI call: layer i on graphs[i], relabelling
     from the ORIGINAL graph in between; bit-identical to the C oracle chain.  gnn_counters_get: the algorithmic work of one iteration."""
