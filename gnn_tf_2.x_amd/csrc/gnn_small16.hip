@@ -123,8 +123,8 @@ __device__ __forceinline__ void small16_layer(const float *b_base, const float (
         // another basic block - and hipcc (ROCm 7.2) then inserts no wait states between an 8-pass MFMA and the v_accvgpr_read of its
         // last destination register: with the linear activation (the read follows at once) feature 3 of every node came out stale
         // (found by test_persistent_small_graph_loop_random_shapes).  Sixteen wait states here cover the 8-pass result.
-        // Guard: `make hazard-scan` (tools/scan_mfma_hazard.py over the ISA listings of every MFMA translation unit, run by build()) fails
-        // the build if such an edge reappears.  Tying the wait to the data instead - acc[0] as an in / out operand of this statement,
+        // Guard: every object's rule in the Makefile scans its ISA listing (tools/scan_mfma_hazard.py, -save-temps=obj) and fails the build
+        // if such an edge reappears.  Tying the wait to the data instead - acc[0] as an in / out operand of this statement,
         // "+v" or "+a" - was tried in round 4 and RE-CREATES the hazard: the compiler then copies the accumulator for the operand
         // (v_accvgpr_read / v_accvgpr_mov) as the first instruction of this block, in front of the s_nop (108 hits in the scan).
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
