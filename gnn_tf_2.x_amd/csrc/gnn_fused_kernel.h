@@ -1307,6 +1307,11 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused(const GnnFusedAr
     if (a.stagger > 0) {
         int rounds = 0;
         if (a.variant & 4) rounds = wave >= GNN_FUSED_WAVES / 2 ? a.stagger : 0;
+#ifdef GNN_DIAG   // experiment of round 4: the four waves on the four SIMDs (bit 7) / pairs of waves (bit 8) of a workgroup start together, so that they ask
+        // for the same weight fragments at about the same time (vector-L1 hits instead of one L2 request per wave)
+        else if (a.variant & 128) rounds = (int)((((unsigned)blockIdx.x * 2 + (unsigned)(wave >> 2)) * 0x9E3779B1u) >> 16) % (unsigned)(a.stagger + 1);
+        else if (a.variant & 256) rounds = (int)((((unsigned)blockIdx.x * 4 + (unsigned)((wave >> 1) & 3)) * 0x9E3779B1u) >> 16) % (unsigned)(a.stagger + 1);
+#endif
         else rounds = (int)((((unsigned)blockIdx.x * GNN_FUSED_WAVES + (unsigned)wave) * 0x9E3779B1u) >> 16) % (unsigned)(a.stagger + 1);
         for (int i = 0; i < rounds; ++i) __builtin_amdgcn_s_sleep(127);
     }
