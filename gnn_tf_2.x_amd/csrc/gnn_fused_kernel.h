@@ -374,6 +374,10 @@ __device__ __forceinline__ void layer_from_regs(f32x16 (&hin)[NI], const float *
 //   hidden, chunk c = 2 ti + q:        k(h, i) = 32 ti + (r & 3) + 8 (r >> 2) + 4 h,  r = 8 q + i   (accumulator register r)
 // gnn_fused.hip packs the weight pieces in the same order: [chunk][out tile][piece][lane][8 bf16].
 // ---------------------------------------------------------------------------------------------------------------------
+// cache-policy bits of the gather's row loads (experiment of round 4: 16 = sc1, the rows bypass the vector L1 and leave it to the weight stream)
+#ifndef GNN_GATHER_AUX
+#define GNN_GATHER_AUX 0
+#endif
 #ifndef GNN_S1_GROUP
 #define GNN_S1_GROUP 1
 #endif
@@ -794,7 +798,7 @@ __device__ __forceinline__ void gather_batch(int my_src, float my_w, __amdgpu_bu
                                              v4f (&x)[GB], std::integer_sequence<int, J...>)
 {
     ((w[J] = row_bcast_f<J>(my_w),
-      x[J] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row_bcast_i<J>(my_src) << 8) + voff0, 0, 0))), ...);
+      x[J] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row_bcast_i<J>(my_src) << 8) + voff0, 0, GNN_GATHER_AUX))), ...);
 }
 
 // Ds == 64, full tile.  Lane group g (16 lanes, 16 B per lane = one 256 B state row per group and instruction) owns the
