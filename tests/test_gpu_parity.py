@@ -796,6 +796,35 @@ def test_wide_states_after_nan_littered_memory():
         loop.close()
 
 
+@pytest.mark.parametrize('n', [65_536, 65_568, 131_072, 131_104, 140_013])
+def test_tile_rounds_static_and_ticketed(n):
+    """How the fused kernel hands out its 32-node tiles (round 4): wave w of the launch takes tiles w and w + W statically (W = 8 waves x
+    256 workgroups = 2,048 on MI355X), further tiles by ticket.  Node counts that end exactly on W tiles, one tile past it, on 2 W, one
+    past that (a single ticketed tile) and with a partial last tile in the ticketed round: every row must be computed exactly once -
+    impl 1 bit-identical to the C oracle, impl 2 within tolerance, over two bodies (the second reads what the first wrote)."""
+    e = _engine()
+    from GNN import GNN_utils as utils
+    rng = np.random.default_rng(n)
+    d, nl, al = 64, 3, 1
+    s = utils.syntheticGraph(n, 6.0, nl, al, 2, seed=n)
+    st = make_mlp(rng, al + 2 * (nl + d), [128, 128, d], 'selu', gain=0.6, bn_random=True)
+    ou = make_mlp(rng, nl + d, [2], 'softmax', bn_random=True)
+    s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
+    arcs = np.concatenate([np.stack([s['src'], s['dst']], 1).astype(np.float32), s['arc_labels']], axis=1)
+    g = dict(nodes=s['nodes'], arcs=arcs, set_mask=np.ones(n, bool), output_mask=np.ones(n, bool),
+             adjT=(s['indptr'], s['adj_src'], s['adj_w']), arcT=(s['indptr'], s['arc_perm'], s['arc_w']))
+    kc, sc, oc = corc.loop_node(g, st, ou, d, 2, 0.0, s0)
+    graph = e.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8))
+    loop = e.Loop(graph, e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True), d, 2, 0.0)
+    assert loop.set_impl(1) == 1
+    loop.set_state0(s0)
+    assert loop.run() == kc and np.array_equal(loop.state(), sc) and np.array_equal(loop.output(), oc)
+    assert loop.set_impl(2) == 2
+    assert loop.run() == kc
+    assert float(np.max(np.abs(loop.state() - sc))) < 2e-6 * max(1.0, float(np.max(np.abs(sc))))
+    loop.close(); graph.close()
+
+
 def test_run_many_runs_small_loops_side_by_side():
     """gnn_loop_run_many: the persistent launches of several small graphs queued on their own streams before any is waited for (they run
     side by side), a graph too large for the persistent path in the same call; every loop's k, state and outputs bit-identical to the C
