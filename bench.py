@@ -139,9 +139,15 @@ def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0, full=None):
                                                                      f'{c_oracle.num_threads()}, {dt1:.1f} s'})
     if full is not None:
         # the oracle is the checker: the GPU Loop on the SAME graph / weights / state0 for the same number of bodies, compared with
-        # the oracle state that was just timed - all N x 64 values (impl 1: bit for bit; default path: max |difference|)
+        # the oracle state that was just timed - all N x 64 values (impl 1: bit for bit; default path: max |difference|) - and with
+        # the float64 shadow of the same Loop on the whole graph (oracle/gnn_oracle_f64.c, the arbiter of fp32 orders)
         graph, mst, mou = full
-        chk = {'iterations': int(k), 'oracle_max_abs_state': float(np.max(np.abs(s_orc)))}
+        t64 = time.perf_counter()
+        k64, s64, o64 = c_oracle.loop_node_f64(g, st, ou, d, iters, 0.0, state0)
+        dt64 = time.perf_counter() - t64
+        chk = {'iterations': int(k), 'oracle_max_abs_state': float(np.max(np.abs(s_orc))),
+               'float64_shadow': f'same Loop in double on the whole graph, {dt64:.1f} s; fp32 oracle vs float64: state '
+                                 f'{float(np.max(np.abs(s_orc - s64))):.3e}, output {float(np.max(np.abs(o_orc - o64))):.3e}'}
         for impl, name in ((1, 'exact_f32_mfma_path'), (2, 'default_split_bf16_path')):
             lp = engine.Loop(graph, mst, mou, d, int(iters), 0.0)
             lp.set_impl(impl)
@@ -150,13 +156,30 @@ def cpu_baseline(s, st, ou, state0, d, iters, engine=None, device=0, full=None):
             sg, og_ = lp.state(), lp.output()
             lp.close()
             chk[name] = {'k_equal': bool(k_gpu == k), 'bit_identical_state': bool(np.array_equal(sg, s_orc)),
-                         'max_abs_diff_state': float(np.max(np.abs(sg - s_orc))), 'max_abs_diff_output': float(np.max(np.abs(og_ - o_orc)))}
+                         'max_abs_diff_state': float(np.max(np.abs(sg - s_orc))), 'max_abs_diff_output': float(np.max(np.abs(og_ - o_orc))),
+                         'max_abs_state_error_vs_float64': float(np.max(np.abs(sg - s64))),
+                         'max_abs_output_error_vs_float64': float(np.max(np.abs(og_ - o64)))}
             del sg, og_
+        del s64, o64
         out['gpu_vs_oracle_full_size'] = chk
-        # the verdict main() acts on: the exact path equals the oracle bit for bit (state, output, k) and the default path stops at the
-        # same k - at the workload's own size and depth (the oracle ran `iters` bodies; the default is the workload's max_iter)
+        # The verdict main() acts on, at the workload's own size and depth (the oracle ran `iters` bodies; the default is the workload's
+        # max_iter).  Exact path: the oracle's bits (state, output, k).  Default path: the same k AND values that add nothing to the float32
+        # noise - no further from float64 than 1.5 x the exact fp32 chain is, state and output (tests/test_gpu_full_size.py asserts the
+        # same).  north_star's literal "1e-5 of the fp32 oracle" is recorded beside it: after 30 bodies of an expansive map (random-init
+        # weights) no float32 ORDER meets it against another - the oracle's own chain is further than that from float64.
         ex, df = chk['exact_f32_mfma_path'], chk['default_split_bf16_path']
-        out['parity_ok'] = bool(ex['k_equal'] and ex['bit_identical_state'] and ex['max_abs_diff_output'] == 0.0 and df['k_equal'])
+        noise_ok = bool(df['max_abs_state_error_vs_float64'] <= 1.5 * ex['max_abs_state_error_vs_float64']
+                        and df['max_abs_output_error_vs_float64'] <= 1.5 * ex['max_abs_output_error_vs_float64'] + 1e-7)
+        scale = max(1.0, chk['oracle_max_abs_state'])
+        out['default_path_values'] = {
+            'criterion': '|default - float64| <= 1.5 x |exact fp32 chain - float64|, state and output, whole graph, workload depth',
+            'ok': noise_ok,
+            'state_error_vs_float64': {'default': df['max_abs_state_error_vs_float64'], 'exact': ex['max_abs_state_error_vs_float64']},
+            'output_error_vs_float64': {'default': df['max_abs_output_error_vs_float64'], 'exact': ex['max_abs_output_error_vs_float64']},
+            'north_star_1e-5_vs_fp32_oracle': {'exact': bool(ex['bit_identical_state']),
+                                               'default': bool(df['max_abs_diff_state'] <= 1e-5 * scale and df['max_abs_diff_output'] <= 1e-5),
+                                               'default_max_abs': df['max_abs_diff_state'], 'scale_max_abs_state': scale}}
+        out['parity_ok'] = bool(ex['k_equal'] and ex['bit_identical_state'] and ex['max_abs_diff_output'] == 0.0 and df['k_equal'] and noise_ok)
     del s_orc, o_orc
     if engine is not None:
         from GNN import GNN_utils as utils
@@ -447,29 +470,34 @@ def main():
     sharded_check = None
     if world > 1:
         with Watchdog(args.rank_timeout, 'sharded-vs-unsharded validation', rank):
-            chk_impl = 1
-            lp_s = engine.Loop(graph, mst, mou, d, 3, 0.0, comm)
-            lp_s.set_impl(chk_impl)
-            lp_s.set_state0(state0[rb:rb + nr])
-            if args.exchange in ('slice', 'slice1'):
-                lp_s.set_slice_exchange(1 if args.exchange == 'slice1' else 2)
-            k_s = lp_s.run()
-            st_s, out_s = lp_s.state(), lp_s.output()
-            lp_s.close()
             whole = engine.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8), device=local_rank)
-            lp_u = engine.Loop(whole, mst, mou, d, 3, 0.0)
-            lp_u.set_impl(chk_impl)
-            lp_u.set_state0(state0)
-            k_u = lp_u.run()
-            st_u, out_u = lp_u.state()[rb:rb + nr], lp_u.output()[rb:rb + nr]
-            lp_u.close(); whole.close()
-            diff = max(float(np.max(np.abs(st_s - st_u))) if nr else 0.0, float(np.max(np.abs(out_s - out_u))) if nr else 0.0)
-            k_bad = 0.0 if k_s == k_u else 1.0
-            diff_all, k_bad_all = comm.allreduce_max(diff), comm.allreduce_max(k_bad)
-            sharded_check = {'bodies': 3, 'impl': chk_impl, 'sharded_vs_unsharded_max_abs_diff': diff_all, 'k_equal': bool(k_bad_all == 0.0),
-                             'ok': bool(diff_all == 0.0 and k_bad_all == 0.0),
+            per_impl, diff_all, k_bad_all = {}, 0.0, 0.0
+            for chk_impl in (1, 2):         # the bit-exact path AND the path that was timed
+                lp_s = engine.Loop(graph, mst, mou, d, 3, 0.0, comm)
+                lp_s.set_impl(chk_impl)
+                lp_s.set_state0(state0[rb:rb + nr])
+                if args.exchange in ('slice', 'slice1'):
+                    lp_s.set_slice_exchange(1 if args.exchange == 'slice1' else 2)
+                k_s = lp_s.run()
+                st_s, out_s = lp_s.state(), lp_s.output()
+                lp_s.close()
+                lp_u = engine.Loop(whole, mst, mou, d, 3, 0.0)
+                lp_u.set_impl(chk_impl)
+                lp_u.set_state0(state0)
+                k_u = lp_u.run()
+                st_u, out_u = lp_u.state()[rb:rb + nr], lp_u.output()[rb:rb + nr]
+                lp_u.close()
+                diff = max(float(np.max(np.abs(st_s - st_u))) if nr else 0.0, float(np.max(np.abs(out_s - out_u))) if nr else 0.0)
+                k_bad = 0.0 if k_s == k_u else 1.0
+                d_i, k_i = comm.allreduce_max(diff), comm.allreduce_max(k_bad)
+                per_impl[f'impl_{chk_impl}'] = {'sharded_vs_unsharded_max_abs_diff': d_i, 'k_equal': bool(k_i == 0.0)}
+                diff_all, k_bad_all = max(diff_all, d_i), max(k_bad_all, k_i)
+            whole.close()
+            sharded_check = {'bodies': 3, 'impls': [1, 2], 'sharded_vs_unsharded_max_abs_diff': diff_all, 'k_equal': bool(k_bad_all == 0.0),
+                             'ok': bool(diff_all == 0.0 and k_bad_all == 0.0), 'per_impl': per_impl,
                              'what': 'every rank: 3 bodies sharded vs the same 3 bodies unsharded on its own device, own rows of state and output, '
-                                     'bit-exact path; max over ranks'}
+                                     'on the bit-exact path and on the default path (a node\'s arithmetic does not depend on its tile or rank: both '
+                                     'must agree bit for bit); max over ranks'}
             del st_s, out_s, st_u, out_u
 
     # the bit-exact fused path (impl 1) on the same inputs, one untimed + one timed Loop: reported beside the headline, and
@@ -588,13 +616,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(s, st, ou, state0, d, args.cpu_iters, engine, local_rank, full=(graph, mst, mou))
             parity_ok = line['cpu_baseline'].pop('parity_ok', None)
+            line['default_path_values'] = line['cpu_baseline'].pop('default_path_values', None)      # what parity_ok says about the TIMED path's values
         if world > 1:
             parity_ok = sharded_check['ok']
         line['parity_ok'] = parity_ok       # null: not checked in this invocation (--no-cpu-baseline)
         print(json.dumps(line), flush=True)
         if parity_ok is False:
             print('bench.py: PARITY FAILED - ' + ('the sharded run differs from the unsharded one' if world > 1 else
-                  'the GPU result differs from the oracle at full size (cpu_baseline.gpu_vs_oracle_full_size)'), file=sys.stderr, flush=True)
+                  'the GPU result differs from the oracle at full size (cpu_baseline.gpu_vs_oracle_full_size; default path: default_path_values)'), file=sys.stderr, flush=True)
             exit_code = 3
     if comm:
         barrier()

@@ -48,6 +48,31 @@ __device__ __forceinline__ GNN_GLOBAL T *gptr_w(T *p) { return (GNN_GLOBAL T *)p
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f gload4(const float *p) { return *(const GNN_GLOBAL v4f *)p; }
+// A/B of round 5 (tools/ab_build.sh): the once-read streams of a tile (CSR ids / weights, row pointers) and / or the new-state row stores
+// with the non-temporal cache policy, so that they displace less of the state table (244 MiB at BASELINE size, re-read ten times per
+// iteration) from L2 / Infinity Cache
+#ifndef GNN_NT_STREAM
+#define GNN_NT_STREAM 0
+#endif
+#ifndef GNN_NT_STORES
+#define GNN_NT_STORES 0
+#endif
+__device__ __forceinline__ float gstream1(const float *p)
+{
+#if GNN_NT_STREAM
+    return __builtin_nontemporal_load((const GNN_GLOBAL float *)p);
+#else
+    return *(const GNN_GLOBAL float *)p;
+#endif
+}
+__device__ __forceinline__ int gstream1(const int *p)
+{
+#if GNN_NT_STREAM
+    return __builtin_nontemporal_load((const GNN_GLOBAL int *)p);
+#else
+    return *(const GNN_GLOBAL int *)p;
+#endif
+}
 __device__ __forceinline__ v2f gload2(const float *p) { return *(const GNN_GLOBAL v2f *)p; }
 __device__ __forceinline__ float gload1(const float *p) { return *(const GNN_GLOBAL float *)p; }
 __device__ __forceinline__ int gload1(const int *p) { return *(const GNN_GLOBAL int *)p; }
@@ -927,7 +952,7 @@ __device__ __forceinline__ void load_tile_fast64(const GnnFusedArgs &a, float *X
         gather_batch<GB>(my_src, my_w, rsrc, voff0, w, x, std::make_integer_sequence<int, GB>{});
         const int nb = base + GB + gl;                                       // ids / weights of the next batch
         my_src = 0; my_w = 0.0f;
-        if (nb < e_end) { my_src = gload1(a.adj_src + nb); my_w = gload1(a.adj_w + nb); }
+        if (nb < e_end) { my_src = gstream1(a.adj_src + nb); my_w = gstream1(a.adj_w + nb); }
 #pragma unroll
         for (int u = 0; u < GB; ++u) {
             GNN_ROW_BOUNDARY(base + u)
@@ -1140,7 +1165,13 @@ __device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, flo
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const v4f *>(xs + 4 * u * KP);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = v[u];
+    for (int u = 0; u < 8; ++u) {
+#if GNN_NT_STORES
+        __builtin_nontemporal_store(v[u], reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u));
+#else
+        *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = v[u];
+#endif
+    }
 }
 
 // The same two for the LAST tile of a range whose row count is not a multiple of 32 (wave-uniform branch in the full-tile kernel: a
@@ -1246,7 +1277,7 @@ __device__ __forceinline__ int tile_rowptr_request(const GnnFusedArgs &a, int ti
     const int64_t i0 = (int64_t)tile * 32;
     if (i0 >= a.n_rows) return 0;
     const int nvalid = (int)((a.n_rows - i0) < 32 ? (a.n_rows - i0) : 32);
-    return (lane <= nvalid) ? gload1(a.indptr + i0 + lane) : 0;
+    return (lane <= nvalid) ? gstream1(a.indptr + i0 + lane) : 0;
 }
 // rows past the end of a partial tile get the last pointer (empty rows); lanes 33.. hold it too
 __device__ __forceinline__ int tile_rowptr_clamp(const GnnFusedArgs &a, int tile, int lane, int raw)
@@ -1263,7 +1294,7 @@ __device__ __forceinline__ void tile_first_ids(const GnnFusedArgs &a, int ip, in
     const int gl = lane & 15, grp = lane >> 4;
     const int e_begin = shfl_i(ip, grp * 8), e_end = shfl_i(ip, grp * 8 + 8);
     src = 0; w = 0.0f;
-    if (e_begin + gl < e_end) { src = gload1(a.adj_src + e_begin + gl); w = gload1(a.adj_w + e_begin + gl); }
+    if (e_begin + gl < e_end) { src = gstream1(a.adj_src + e_begin + gl); w = gstream1(a.adj_w + e_begin + gl); }
 }
 
 template <int N>

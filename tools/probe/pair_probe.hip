@@ -42,7 +42,9 @@ __device__ __forceinline__ void gather16(int my_id, float my_w, __amdgpu_buffer_
 // PX: partner = wave ^ PX (1: the partner sits on another SIMD; 4: the two waves of one SIMD)
 // S2: 2 hand-overs per layer boundary (readers done -> writers done: the piece buffer is re-used in place, the LDS budget that fits four pairs
 //     per CU) or 1 (two piece buffers: does not fit, shown as the bound)
-template <int V, int WD, int PX, int S2>
+// XV: vector-ALU instructions a wave issues OUTSIDE the MFMA gaps per tile (the layer-0 operand cut before the first meeting: 220, and the half of
+//     every publish step that has no MFMAs of its own wave to hide behind: 2 x 150) - 0 = everything interleaved (the optimistic bound)
+template <int V, int WD, int PX, int S2, int XV = 0>
 __global__ void __launch_bounds__(512, 2) k_pair32(const int *idx, const float *ew, int tiles, const float *table, float *out, int *ctr, const v4f *img,
                                                    const float *own, float *dst)
 {
@@ -108,6 +110,8 @@ __global__ void __launch_bounds__(512, 2) k_pair32(const int *idx, const float *
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < XV * 220 / 520; ++q) vv[q & 7] = __builtin_fmaf(vv[q & 7], 1.0000001f, 0.5f);      // layer-0 cut of the own rows
         meet();                                                      // the tile is complete
         // ---- dense layers: fragments of this wave's feature half, every fragment feeds two MFMAs, B operands from LDS ----
         v4f w[WD];
@@ -139,6 +143,8 @@ __global__ void __launch_bounds__(512, 2) k_pair32(const int *idx, const float *
             }
         };
         auto publish = [&](int chunks) {                             // this wave's output features as 3 pieces per chunk
+#pragma unroll
+            for (int q = 0; q < XV * 150 / 520; ++q) vv[q & 7] = __builtin_fmaf(vv[q & 7], 1.0000001f, 0.5f);  // activation + cut of the last output tile
             if (S2 == 2) meet();                                     // both waves are done READING the buffer
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -304,12 +310,12 @@ int main(int argc, char **argv)
     hipMemset(img, 0, 512 * 1024);
     const size_t lds32 = 8 * 32 * 68 * 4, ldsp = 4 * (32 * 84 + 8 * 3 * 256) * 4 + 64;
     printf("# %d tiles of 32 nodes (%ld nodes), 10 random 256-byte rows per node, 252 KiB of weight fragments and 504 MFMAs per tile\n", tiles32, (long)tiles32 * 32);
-#define RUNP(V, WD, PX, S2)                                                                                                         \
+#define RUNP(V, WD, PX, S2, ...)                                                                                                         \
     {                                                                                                                               \
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair32<V, WD, PX, S2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        float ms = timeit([&] { hipLaunchKernelGGL((k_pair32<V, WD, PX, S2>), 256, 512, ldsp, 0, idx, ew, tiles32, table, out, ctr, img, own, dst); }, ctr); \
-        printf("pair32  partner = wave ^ %d (%s)  %d meetings per layer boundary  V=%d VALU/MFMA  weights %2d ahead: %.3f ms\n", PX,   \
-               PX == 1 ? "other SIMD" : "same SIMD ", S2, V, WD, ms);                                                                \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pair32<V, WD, PX, S2, ##__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        float ms = timeit([&] { hipLaunchKernelGGL((k_pair32<V, WD, PX, S2, ##__VA_ARGS__>), 256, 512, ldsp, 0, idx, ew, tiles32, table, out, ctr, img, own, dst); }, ctr); \
+        printf("pair32  partner = wave ^ %d (%s)  %d meetings per layer boundary  V=%d VALU/MFMA  weights %2d ahead  exposed VALU (%s): %.3f ms\n", PX,   \
+               PX == 1 ? "other SIMD" : "same SIMD ", S2, V, WD, #__VA_ARGS__, ms);                                                                \
         fflush(stdout);                                                                                                             \
     }
 #define RUN32(V, WD)                                                                                                                \
@@ -322,6 +328,7 @@ int main(int argc, char **argv)
     RUNP(4, 6, 1, 2) RUNP(6, 6, 1, 2) RUNP(4, 6, 4, 2) RUNP(6, 6, 4, 2)
     RUNP(4, 6, 1, 1) RUNP(4, 6, 4, 1)
     RUNP(4, 12, 1, 2) RUNP(6, 12, 1, 2) RUNP(4, 12, 4, 2)
-    RUN32(4, 8)
+    RUNP(4, 6, 1, 2, 520) RUNP(6, 6, 1, 2, 520) RUNP(3, 6, 1, 2, 520) RUNP(5, 6, 1, 2, 520)
+    RUN32(4, 4) RUN32(6, 4) RUN32(4, 8)
     return 0;
 }
