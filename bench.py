@@ -388,6 +388,7 @@ def main():
                          'return all-to-all as ONE grouped call behind the aggregation; slice1: block by block on a second stream beside it '
                          '(gnn_loop_set_slice_exchange(l, 1): verified in loopback groups and over the tests\' stand-in transport, never on '
                          'RCCL with more than one rank - until it has been, the bench keeps to the one-shot form)')
+    ap.add_argument('--tile-form', type=int, default=0, help='default path: 1 = one wave per 32-node tile (k_fused), 2 = a wave pair per tile (k_fused_pair), 0 = the library\'s choice')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the untimed configs[1] / configs[4] figures under config.other_configs')
     ap.add_argument('--cpu-iters', type=int, default=30, help='bodies of the CPU-baseline sample = depth of the full-size parity check (default: the workload\'s max_iter)')
@@ -438,6 +439,7 @@ def main():
     mou = engine.Mlp(ou['weights'], ou['activations'], True, device=local_rank)
     loop = engine.Loop(graph, mst, mou, d, args.max_iter, 0.0, comm)
     impl_used = loop.set_impl(args.impl)
+    tile_form = loop.set_tile_form(args.tile_form)
     loop.set_state0(state0[rb:rb + nr])
     if world > 1 and args.exchange in ('slice', 'slice1'):
         graph.set_full_adjacency(n, s['indptr'], s['adj_src'], s['adj_w'])
@@ -576,6 +578,7 @@ def main():
                                    'pieces (6 piece products, fp32 accumulate; error per product <= 3*2^-24)',
                                 1: 'fused gather+MLP kernel, dense layers on the f32 MFMA (bit-identical to the oracle)',
                                 0: 'one kernel per TF op (unfused)'}[impl_used],
+                       'tile_form': {1: 'one wave per 32-node tile (k_fused)', 2: 'wave pair per 32-node tile (k_fused_pair)'}.get(tile_form, 'n/a') if impl_used == 2 else 'n/a',
                        'exact_f32_mfma_path': exact,
                        'cold_aggregates_ms_per_step': cold_ms,
                        'pcie_inclusive_updates_per_s': nr * k_e2e / e2e_s},

@@ -20,7 +20,7 @@ EXPORTS = ['gnn_last_error', 'gnn_version', 'gnn_device_count', 'gnn_device_sync
            'gnn_mlp_create', 'gnn_mlp_set_weights', 'gnn_mlp_get_weights', 'gnn_mlp_reset_optimizer', 'gnn_mlp_forward', 'gnn_mlp_destroy', 'gnn_loop_create',
            'gnn_loop_set_state0', 'gnn_loop_run', 'gnn_loop_get_state', 'gnn_loop_get_output', 'gnn_loop_readout', 'gnn_loop_set_edge_readout', 'gnn_loop_train_step',
            'gnn_loop_train_forward', 'gnn_loop_train_backward', 'gnn_loop_arm_optimizer', 'gnn_loop_optimizer_step', 'gnn_loop_update_moving_statistics', 'gnn_loss_grad',
-           'gnn_counters_get', 'gnn_lgnn_run', 'gnn_loop_run_many', 'gnn_loop_set_impl', 'gnn_loop_gate_info', 'gnn_loop_set_persistent', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_get_exchange_timing', 'gnn_loop_destroy', 'gnn_shard_range',
+           'gnn_counters_get', 'gnn_lgnn_run', 'gnn_loop_run_many', 'gnn_loop_set_impl', 'gnn_loop_gate_info', 'gnn_loop_set_persistent', 'gnn_loop_set_tile_form', 'gnn_loop_drop_cached_aggregates', 'gnn_loop_set_profiling', 'gnn_loop_get_timing', 'gnn_loop_get_exchange_timing', 'gnn_loop_destroy', 'gnn_shard_range',
            'gnn_comm_unique_id', 'gnn_comm_create', 'gnn_comm_allreduce_max', 'gnn_comm_destroy', 'gnn_halo_plan', 'gnn_graph_create_halo',
            'gnn_comm_create_loopback', 'gnn_graph_set_full_adjacency', 'gnn_loop_set_slice_exchange', 'gnn_loop_run_group', 'gnn_loop_readout_group', 'gnn_graph_update_labels_group']
 
@@ -574,6 +574,13 @@ class Loop:
         used = C.c_int(0)
         _check(lib().gnn_loop_set_persistent(self._h, C.c_int(bool(enable)), C.byref(used)))
         return bool(used.value)
+
+    def set_tile_form(self, form: int) -> int:
+        """gnn_loop_set_tile_form: 1 = one wave per 32-node tile, 2 = a wave pair per tile, 0 = the library's choice; returns the form the
+        next run takes (0: the fused path does not cover this loop)."""
+        used = C.c_int(0)
+        _check(lib().gnn_loop_set_tile_form(self._h, C.c_int(int(form)), C.byref(used)))
+        return used.value
 
     def counters(self) -> dict:
         """gnn_counters_get: algorithmic bytes / FLOPs of one iteration on the owned rows, and the last run's iteration count and times."""

@@ -286,6 +286,7 @@ struct gnn_loop {
     bool have_state0 = false, ran = false;
     bool graph_ready_seen = false;          // this loop's stream has waited for the graph's creation-time fills
     int impl_req = 1, impl_used = 0;
+    int tile_form = 0;                      // gnn_loop_set_tile_form: 0 library's choice, 1 one wave per tile, 2 wave pair per tile
     int32_t *ng_ip = nullptr, *ng_node = nullptr;   // cached NodeGraph^T (graph readout)
     float *ng_w = nullptr, *ng_out = nullptr, *ng_part = nullptr;   // ng_part [world, G, T]: per-rank partial readouts
     std::vector<int32_t> ng_key;
@@ -354,6 +355,7 @@ void gnn_train_arena_free(gnn_loop *l);
 
 // gnn_fused.hip
 bool gnn_fused_supported(const gnn_loop *l);
+bool gnn_fused_pair_selected(const gnn_loop *l);   // the default path's bodies run as k_fused_pair (wave pair per tile) rather than k_fused
 int gnn_fused_prepare(gnn_loop *l);
 int gnn_fused_pack(gnn_mlp *m, int nlc);
 int gnn_fused_iteration(gnn_loop *l, int k);

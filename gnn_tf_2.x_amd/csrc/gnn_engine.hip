@@ -1369,6 +1369,14 @@ extern "C" int gnn_loop_set_persistent(gnn_loop *l, int enable, int *used)
     return GNN_OK;
 }
 
+extern "C" int gnn_loop_set_tile_form(gnn_loop *l, int form, int *used)
+{
+    ARGCHK(l && form >= 0 && form <= 2, "form must be 0 (library's choice), 1 (one wave per tile) or 2 (wave pair per tile)");
+    l->tile_form = form;
+    if (used) *used = (l->impl_req >= 1 && gnn_fused_supported(l)) ? (gnn_fused_pair_selected(l) ? 2 : 1) : 0;
+    return GNN_OK;
+}
+
 extern "C" int gnn_loop_set_profiling(gnn_loop *l, int enable)
 {
     ARGCHK(l, "loop is NULL");

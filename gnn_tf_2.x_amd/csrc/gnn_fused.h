@@ -102,6 +102,9 @@ bool gnn_fused_launch_l1(int act, int nt, int ntl, const GnnFusedArgs &a, unsign
 bool gnn_fused_launch_s1(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_s2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_s3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+// wave-pair form (gnn_fused_pair_kernel.h: split arithmetic, state width 64, 128-wide hidden layers, 9 layer-0 chunks): gnn_fused_p{2,3}.hip
+bool gnn_fused_launch_p2(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
+bool gnn_fused_launch_p3(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 // 16-node-tile kernel (split arithmetic, state width 64), 2 / 3 layers; nf: 16-feature tiles of the hidden layers (4 or 8)
 bool gnn_fused_launch_h2(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_h3(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

@@ -109,7 +109,33 @@ size_t lds_bytes(const FusedPlan &p)
     return (size_t)GNN_FUSED_WAVES * 32 * std::max(p.KP, p.KPs) * sizeof(float) + 128 + GNN_FUSED_WAVES * 36 * sizeof(int) + (3 + 2) * 32 * 4 * sizeof(float) + 16;
 }
 
+// the wave-pair form (gnn_fused_pair_kernel.h) covers the tuned shape family only: split arithmetic, state width 64, two or three layers, 128-wide
+// hidden layers, a concat of nine K = 16 chunks
+constexpr int PAIR_CH0 = 9;
+bool pair_covers(const FusedPlan &p, int ds) { return ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && p.chunks[0] == PAIR_CH0; }
+int pair_xs(const FusedPlan &p)       // row stride of a pair's gather tile X' (the LDS columns behind the own state), a multiple of 4 with XS / 4 odd
+{
+    int xs = 16 * p.chunks[0] - 64 + 4;
+    if ((xs / 4) % 2 == 0) xs += 4;
+    return xs;
+}
+// four pairs x (X'[32][XS] + P[CH0][3][64] x 16 B), 16 control words, 8 x 20 row pointers, staged vectors, slack
+size_t pair_lds_bytes(const FusedPlan &p)
+{
+    return sizeof(float) * ((size_t)4 * (32 * pair_xs(p) + p.chunks[0] * 768) + 16 + GNN_FUSED_WAVES * 20 + 3 * 32 * 2 + 2 * 32 * 4) + 128;
+}
+// the library's choice between the two forms of the default path's kernel (gnn_loop_set_tile_form(l, 0)); DESIGN.md 4.1 has the measurements
+constexpr int GNN_TILE_FORM_DEFAULT = 1;
+
 }   // namespace
+
+bool gnn_fused_pair_selected(const gnn_loop *l)
+{
+    FusedPlan p;
+    if (l->impl_req != 2 || l->slice_mode || !make_plan(l->st, l->NLc, p)) return false;
+    const int form = l->tile_form ? l->tile_form : GNN_TILE_FORM_DEFAULT;
+    return form == 2 && pair_covers(p, l->Ds) && pair_lds_bytes(p) <= 160 * 1024;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
@@ -432,7 +458,19 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         }
     }
 #endif
-    if (wide) ok = true;
+    bool pair = false;
+    if (!wide && split && gnn_fused_pair_selected(l)) {
+        // wave-pair form: four pairs per workgroup, one workgroup per CU; the tile counters, gates and flags are k_fused's
+        GnnFusedArgs ap = a;
+        ap.KP = pair_xs(p);
+        ap.full_tiles = 1; ap.tile_base = 0;
+        const unsigned grid_p = (unsigned)std::min<int64_t>((int64_t)n_cu, (n_tiles64 + 3) / 4);
+        ap.stagger = n_tiles64 >= (int64_t)4 * 4 * grid_p ? stagger_rounds : (n_tiles64 > (int64_t)4 * grid_p ? GNN_FUSED_SPREAD_SMALL_DEFAULT : 0);
+        const size_t lds_p = pair_lds_bytes(p);
+        ap.lds_floats = gnn_poison_enabled() ? (int)(lds_p / sizeof(float)) : 0;
+        pair = p.layers == 2 ? gnn_fused_launch_p2(p.act, ap, grid_p, lds_p, l->stream) : gnn_fused_launch_p3(p.act, ap, grid_p, lds_p, l->stream);
+    }
+    if (wide || pair) ok = true;
     else {
     // Experiment of round 3 (diagnostic build, GNN_FUSED_TILE16=1): 16-node tiles on v_mfma_f32_16x16x32_bf16, three waves per SIMD
     // (experiments/gnn_fused16_kernel.h).  Correct, and slower than this kernel at every size from 31 k to 500 k nodes:

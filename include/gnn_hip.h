@@ -249,6 +249,15 @@ int gnn_loop_gate_info(const gnn_loop *l, int *last_run_repeated, int *repeats_t
  * ONE persistent launch when impl is 1 or 2 (exact f32-MFMA arithmetic in both cases, bit-identical to the oracle).  enable = 0
  * keeps such a loop to one launch per body; *used (may be NULL) tells whether the persistent launch will be taken. */
 int gnn_loop_set_persistent(gnn_loop *l, int enable, int *used);
+/* Which form of the fused iteration kernel runs the bodies of GNN/GNN.py:223-242 on the default path (impl 2) when both cover the
+ * net (state width 64, two or three Dense layers, 128-wide hidden layers, concat width 129 .. 144, no feature-sliced exchange):
+ *   form 1  one wave owns a 32-node tile from gather to store (k_fused);
+ *   form 2  a wave PAIR shares the tile, each wave gathering 16 of its nodes and producing half of every layer's output features
+ *           (k_fused_pair);
+ *   form 0  the library's choice (default).
+ * The two forms evaluate the same arithmetic per node: states, outputs and k are identical bit for bit.  *used (may be NULL) = the form
+ * the next run will take (1 or 2; 0 when the fused path does not cover the loop at all). */
+int gnn_loop_set_tile_form(gnn_loop *l, int form, int *used);
 /* per-kernel HIP-event timing of the last gnn_loop_run when profiling was enabled:
  * avg_iter_ms = mean duration of the per-iteration kernel(s), total_ms = whole loop on the stream. */
 int gnn_loop_set_profiling(gnn_loop *l, int enable);
