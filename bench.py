@@ -443,7 +443,7 @@ def main():
     loop.set_state0(state0[rb:rb + nr])
     if world > 1 and args.exchange in ('slice', 'slice1'):
         graph.set_full_adjacency(n, s['indptr'], s['adj_src'], s['adj_w'])
-        loop.set_slice_exchange(1 if args.exchange == 'slice1' else 2)
+        loop.set_slice_exchange(True, form='pipelined' if args.exchange == 'slice1' else 'oneshot')
 
     def barrier(value=0.0):
         engine._check(engine.lib().gnn_device_synchronize(local_rank))
@@ -479,7 +479,7 @@ def main():
                 lp_s.set_impl(chk_impl)
                 lp_s.set_state0(state0[rb:rb + nr])
                 if args.exchange in ('slice', 'slice1'):
-                    lp_s.set_slice_exchange(1 if args.exchange == 'slice1' else 2)
+                    lp_s.set_slice_exchange(True, form='pipelined' if args.exchange == 'slice1' else 'oneshot')
                 k_s = lp_s.run()
                 st_s, out_s = lp_s.state(), lp_s.output()
                 lp_s.close()

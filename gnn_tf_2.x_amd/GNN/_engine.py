@@ -475,13 +475,16 @@ class Loop:
         return dict(loss=float(loss.value), k=float(k.value), grads_state=split(gs, shp_s), grads_output=split(go, shp_o),
                     bn_batch_state=bns[:kk], bn_batch_output=bno)
 
-    def set_slice_exchange(self, on=2):
-        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows.  on = 2 (the default, also for
-        True): whole slice, then one grouped all-to-all; on = 1: the return all-to-all runs block by block beside the aggregation on a second
-        stream of the communicator - bit-identical in loopback groups and over the tests' stand-in transport, but not the default until it has
-        run once over RCCL with more than one rank; on = 0 / False: off."""
-        form = 2 if on is True else int(on)
-        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(form)))
+    def set_slice_exchange(self, on=True, form=None):
+        """gnn_loop_set_slice_exchange: feature-sliced all-to-all instead of the all-gather of state rows.  on: any truthy value (True, 1,
+        numpy.bool_) switches it on in the default form, falsy switches it off.  form (keyword, only with on): 'oneshot' (default: whole slice,
+        then one grouped all-to-all) or 'pipelined' (the return all-to-all block by block beside the aggregation on a second stream of the
+        communicator - bit-identical in loopback groups and over the tests' stand-in transport, but never yet run over RCCL with more than
+        one rank, hence never implied by `on`)."""
+        if form not in (None, 'oneshot', 'pipelined'):
+            raise ValueError("form must be 'oneshot' or 'pipelined'")
+        code = 0 if not on else (1 if form == 'pipelined' else 2)
+        _check(lib().gnn_loop_set_slice_exchange(self._h, C.c_int(code)))
 
     def update_moving_statistics(self, bn_momentum_state: float = 0.99, bn_momentum_output: float = 0.99):
         """gnn_loop_update_moving_statistics: the moving statistics of both nets from the last train_forward, on the device."""

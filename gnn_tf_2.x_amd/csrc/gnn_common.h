@@ -122,6 +122,9 @@ __device__ __forceinline__ void gnn_flag_raise(int *flag_rank_base)
 // tests/test_gpu_parity.py), and it only matters for the body at which a loop stops - where, by definition, nothing moves robustly.
 #define GNN_BAND_ABS 1e-5f
 #define GNN_BAND_REL 1e-3f
+// a node is borderline when its test sits within the band of the threshold; a node whose old state AND movement are exactly zero (an isolated or
+// dead node: norm 0, distance 0, band 0) is decided identically by every arithmetic and is NOT borderline
+__device__ __forceinline__ bool gnn_gate_borderline(float root, float rhs, float band) { return band > 0.0f && __builtin_fabsf(root - rhs) <= band; }
 // The same in two steps, for the hot path: peek() requests the three words early (the flags only ever go from 0 to 1, so a value read
 // early is at worst a reason for a redundant OR), raise() decides at the end of the tile without waiting for memory.
 struct GnnFlagPeek { int c0, c1, c2; };

@@ -1959,9 +1959,18 @@ static int run_loops(gnn_loop **ls, int n, float *k_out)
     // Every rank reads the same exchanged flag words, so all ranks of a sharded job take this branch together.
     for (int r = 0; r < n; ++r) ls[r]->last_run_rerun = false;
     if (!small && fused[0] && ls[0]->impl_req == 2 && ls[0]->kfinal_host[2] != 0) {
+        static bool told = false;       // once per process: the caller gets the exact path's results, at the exact path's price
+        if (!told && !getenv("GNN_QUIET")) {
+            told = true;
+            fprintf(stderr, "libgnn_hip: a gate of a default-path Loop was decided by a borderline node (no robust mover): the Loop is repeated on the "
+                            "bit-exact path and its k / state / output are returned (gnn_loop_gate_info counts these; gnn_loop_set_impl(l, 1) avoids the double run)\n");
+        }
         for (int r = 0; r < n; ++r) ls[r]->impl_req = 1;
         rc = run_loops(ls, n, k_out);
-        for (int r = 0; r < n; ++r) { ls[r]->impl_req = 2; ls[r]->last_run_rerun = true; ++ls[r]->certified_reruns; }
+        for (int r = 0; r < n; ++r) {
+            ls[r]->impl_req = 2;
+            if (rc == GNN_OK) { ls[r]->last_run_rerun = true; ++ls[r]->certified_reruns; }
+        }
         return rc;
     }
     for (int r = 0; r < n; ++r) {
@@ -2034,6 +2043,7 @@ extern "C" int gnn_loop_run_many(gnn_loop **loops, int n, float *k_out /* [n] */
         gnn_loop *l = loops[i];
         bool fused = false;
         if ((rc = loop_prepare(l, &fused))) return drain(rc);
+        l->last_run_rerun = false;                      // (the persistent path is exact arithmetic and never repeats; run_loops sets it for the others)
         if (!(fused && gnn_small_supported(l))) continue;
         const long wgs = (long)((l->g->n_rows + 15) / 16);      // upper bound of the launch's grid (16- or 32-node tiles)
         if (in_flight && in_flight + wgs > cap && (rc = collect())) return drain(rc);

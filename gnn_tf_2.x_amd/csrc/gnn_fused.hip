@@ -385,8 +385,8 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     static unsigned long long *stamp_buf = nullptr;
     const size_t n_waves = n_tiles;
     if (stamp_file && k == 1) {
-        if (!stamp_buf) HIPCHK(gnn_dev_malloc((void **)&stamp_buf, n_waves * 8 * sizeof(unsigned long long)));
-        HIPCHK(hipMemsetAsync(stamp_buf, 0, n_waves * 8 * sizeof(unsigned long long), l->stream));
+        if (!stamp_buf) HIPCHK(gnn_dev_malloc((void **)&stamp_buf, n_waves * 16 * sizeof(unsigned long long)));      // (8 slots per tile: k_fused; 16: k_fused_pair)
+        HIPCHK(hipMemsetAsync(stamp_buf, 0, n_waves * 16 * sizeof(unsigned long long), l->stream));
         a.stamps = stamp_buf;
     }
 #endif
@@ -504,7 +504,7 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);
 #ifdef GNN_DIAG
     if (a.stamps) {
-        std::vector<unsigned long long> host(n_waves * 8);
+        std::vector<unsigned long long> host(n_waves * (pair ? 16 : 8));
         HIPCHK(hipStreamSynchronize(l->stream));
         HIPCHK(hipMemcpy(host.data(), stamp_buf, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         if (FILE *f = fopen(stamp_file, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }

@@ -47,6 +47,7 @@ template <class T>
 __device__ __forceinline__ GNN_GLOBAL T *gptr_w(T *p) { return (GNN_GLOBAL T *)p; }
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v4i_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4f gload4(const float *p) { return *(const GNN_GLOBAL v4f *)p; }
 // A/B of round 5 (tools/ab_build.sh): the once-read streams of a tile (CSR ids / weights, row pointers) and / or the new-state row stores
 // with the non-temporal cache policy, so that they displace less of the state table (244 MiB at BASELINE size, re-read ten times per
@@ -54,9 +55,21 @@ __device__ __forceinline__ v4f gload4(const float *p) { return *(const GNN_GLOBA
 #ifndef GNN_NT_STREAM
 #define GNN_NT_STREAM 0
 #endif
-#ifndef GNN_NT_STORES
-#define GNN_NT_STORES 0
+#ifndef GNN_STORE_AUX
+#define GNN_STORE_AUX 0       // cache-policy bits of the new-state row stores: 0 default, 2 nt, 16 sc1, 1 sc0 (combinations: A/B of round 5)
 #endif
+// 16 bytes of a new-state row at base (wave-uniform) + off floats (per lane)
+__device__ __forceinline__ void gstore_row4(float *base, int64_t off, v4f v)
+{
+#if GNN_STORE_AUX == 0
+    *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(base) + off) = v;
+#elif GNN_STORE_AUX == 2
+    __builtin_nontemporal_store(v, reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(base) + off));
+#else
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_, v), rs, (int)(off * 4), 0, GNN_STORE_AUX);
+#endif
+}
 __device__ __forceinline__ float gstream1(const float *p)
 {
 #if GNN_NT_STREAM
@@ -1084,7 +1097,7 @@ __device__ __forceinline__ void check_store_generic(const GnnFusedArgs &a, float
     if (moved_out) *moved_out = __any(moved) ? 1 : 0;
     else if (a.certify) {      // split arithmetic: certified gate
         const float band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
-        const int robust = voter && (root > rhs + band), border = voter && (__builtin_fabsf(root - rhs) <= band);
+        const int robust = voter && (root > rhs + band), border = voter && gnn_gate_borderline(root, rhs, band);
         const bool am = __any(moved), ar = __any(robust), ab = __any(border);
         if (lane == 0) gnn_flag_raise_certified(a.flag_out, am, ar, ab);
     }
@@ -1155,23 +1168,17 @@ __device__ __forceinline__ void finish_fast64_aligned(const GnnFusedArgs &a, flo
     const float root = sqrtf(d2), nrm = sqrtf(o2);
     {   // certified gate (gnn_common.h): both half-lanes of a node hold the same sums
         const float rhs = a.thr * nrm, band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
-        const bool am = __any(root > rhs), ar = __any(root > rhs + band), ab = __any(__builtin_fabsf(root - rhs) <= band);
+        const bool am = __any(root > rhs), ar = __any(root > rhs + band), ab = __any(gnn_gate_borderline(root, rhs, band));
         if (lane == 0) gnn_flag_raise_peeked(a.flag_out, peek, am, ar, ab);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float *dst = a.state_nxt + i0 * 64 + lane * 4;                           // flat element 256 u + 4 lane = row 4u + lane/16
+    const int64_t dst = i0 * 64 + lane * 4;                                  // flat element 256 u + 4 lane = row 4u + lane/16
     const float *xs = X + (lane >> 4) * KP + c_aggs + (lane & 15) * 4;
     v4f v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const v4f *>(xs + 4 * u * KP);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-#if GNN_NT_STORES
-        __builtin_nontemporal_store(v[u], reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u));
-#else
-        *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = v[u];
-#endif
-    }
+    for (int u = 0; u < 8; ++u) gstore_row4(a.state_nxt, dst + 256 * u, v[u]);
 }
 
 // The same two for the LAST tile of a range whose row count is not a multiple of 32 (wave-uniform branch in the full-tile kernel: a
@@ -1230,7 +1237,7 @@ __device__ __forceinline__ void finish_fast64_partial(const GnnFusedArgs &a, flo
     {   // certified gate (gnn_common.h); rows past the end of the range do not vote
         const bool voter = (lane & 31) < nvalid;
         const float rhs = a.thr * nrm, band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
-        const bool am = __any(voter && root > rhs), ar = __any(voter && root > rhs + band), ab = __any(voter && __builtin_fabsf(root - rhs) <= band);
+        const bool am = __any(voter && root > rhs), ar = __any(voter && root > rhs + band), ab = __any(voter && gnn_gate_borderline(root, rhs, band));
         if (lane == 0) gnn_flag_raise_certified(a.flag_out, am, ar, ab);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -261,6 +261,21 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
     const int nvalid = (int)((a0.n_rows - i0) < 32 ? (a0.n_rows - i0) : 32);
     GnnFusedArgs a = a0;
     asm volatile("" : "+s"(a.state_cur), "+s"(a.state_nxt), "+s"(a.inv), "+s"(a.adj_src), "+s"(a.adj_w));
+#ifndef GNN_DIAG
+#define GNN_PSTAMP(slot) do { } while (0)
+#else     // diagnostic build, GNN_FUSED_STAMPS=<file>: s_memtime of side 0 at the phase boundaries of a tile (16 slots per tile)
+    unsigned long long *stamp = (a.stamps && side == 0) ? a.stamps + ((size_t)tile << 4) : nullptr;
+#define GNN_PSTAMP(slot)                                                                     \
+    do {                                                                                     \
+        if (stamp) {                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+            if (lane == 0) stamp[slot] = t_;                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+        }                                                                                    \
+    } while (0)
+#endif
+    GNN_PSTAMP(0);
     if (lane <= 16) ipt[lane] = ip_cur;
     const int ip_next_raw = pair_rowptr_request(a, next_tile, side, lane);
     // ---- own state of this side's 16 rows in operand order: floats [16 c + 8 h + 4 j', +4) of row nl for c = cp, cp + 2 ----
@@ -298,6 +313,7 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
             }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    GNN_PSTAMP(1);
     // ---- layer-0 operand: this side's rows cut into pieces, chunks of parity cp per lane ----
     {
         const int pl = 16 * side + nl + 32 * ch;                  // MFMA lane (node of the tile, k-half) this lane produces the pieces of
@@ -323,15 +339,19 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
             }
         }
     }
+    GNN_PSTAMP(2);
     pair_meet(words, wave, partner, phase, lane);                 // (1) layer-0 operand complete
+    GNN_PSTAMP(3);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(a.Ws_base), 0, a.ws_bytes, 0x00020000);
     const int wv = lane * 16;
     f32x16 out[1];
     {
         f32x16 h1[2];
         pair_layer<CH0, 2, NT * 3072, 3>(P, lane, wrs, wv, a.ws_off[0] + side * 6144, h1, hb, 2 * side, half);
+        GNN_PSTAMP(4);
         v4i pp[4][3];
         pair_cut<2, ACT>(h1, pp);
+        GNN_PSTAMP(5);
         pair_meet(words, wave, partner, phase, lane);             // (2) both waves have read the layer-0 operand
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -339,19 +359,24 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
             for (int pc = 0; pc < 3; ++pc) P[((4 * side + c) * 3 + pc) * 64 + lane] = pp[c][pc];
     }
     pair_meet(words, wave, partner, phase, lane);                 // (3) hidden activations of layer 0 complete
+    GNN_PSTAMP(6);
     if constexpr (LAYERS == 3) {
         f32x16 h2[2];
         pair_layer<2 * NT, 2, NT * 3072, 3>(P, lane, wrs, wv, a.ws_off[1] + side * 6144, h2, hb + 32 * NT, 2 * side, half);
+        GNN_PSTAMP(7);
         v4i pp[4][3];
         pair_cut<2, ACT>(h2, pp);
+        GNN_PSTAMP(8);
         pair_meet(words, wave, partner, phase, lane);             // (4)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) P[((4 * side + c) * 3 + pc) * 64 + lane] = pp[c][pc];
         pair_meet(words, wave, partner, phase, lane);             // (5)
+        GNN_PSTAMP(9);
     }
     pair_layer<2 * NT, 1, NTL * 3072, 4>(P, lane, wrs, wv, a.ws_off[LAYERS - 1] + side * 3072, out, ep, side, half);
+    GNN_PSTAMP(10);
     // ---- requests behind the last weight loads (vector-memory results return in order): ticket, next tile's first ids, gate words ----
     int next2_tile = 0x3fffffff;
     if (third_round && side == 0 && lane == 0) next2_tile = atomicAdd(a0.tile_ctr, 1) + 2 * PAIRS;
@@ -369,7 +394,9 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f *>(xrow + 8 * q) = v4f{out[0][4 * q], out[0][4 * q + 1], out[0][4 * q + 2], out[0][4 * q + 3]};
     }
+    GNN_PSTAMP(11);
     pair_meet(words, wave, partner, phase, lane);                 // (6) the new state of all 32 nodes is in LDS
+    GNN_PSTAMP(12);
     {   // condition() of this side's 16 nodes: lane (nl, ch, cp) holds the old features [16 c + 8 ch, +8), c = cp, cp + 2
         float d2 = 0.0f, o2 = 0.0f;
         const float *xn = XR + nl * XS + ca + 16 * cp + 8 * ch;
@@ -385,20 +412,23 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
         const float root = sqrtf(d2), nrm = sqrtf(o2);
         const bool voter = 16 * side + nl < nvalid;
         const float rhs = a.thr * nrm, band = GNN_BAND_ABS * nrm + GNN_BAND_REL * rhs;
-        const bool am = __any(voter && root > rhs), ar = __any(voter && root > rhs + band), ab = __any(voter && __builtin_fabsf(root - rhs) <= band);
+        const bool am = __any(voter && root > rhs), ar = __any(voter && root > rhs + band), ab = __any(voter && gnn_gate_borderline(root, rhs, band));
         if (lane == 0) gnn_flag_raise_peeked(a.flag_out, peek, am, ar, ab);
         // coalesced row stores of this side's 16 rows
-        float *dst = a.state_nxt + (i0 + 16 * side) * 64 + lane * 4;         // flat element 256 u + 4 lane = row 4 u + lane / 16
+        const int64_t dst = (i0 + 16 * side) * 64 + lane * 4;                // flat element 256 u + 4 lane = row 4 u + lane / 16
         const float *xs = XR + (lane >> 4) * XS + ca + (lane & 15) * 4;
         v4f v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f *>(xs + 4 * u * XS);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (16 * side + 4 * u + (lane >> 4) < nvalid) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + 256 * u) = v[u];
+            if (16 * side + 4 * u + (lane >> 4) < nvalid) gstore_row4(a.state_nxt, dst + 256 * u, v[u]);
     }
+    GNN_PSTAMP(13);
     if (side == 0 && lane == 0) words[8 + pair] = next2_tile;
     pair_meet(words, wave, partner, phase, lane);                 // (7) the tile buffers are free; the leader's ticket is in its slot
+    GNN_PSTAMP(14);
+#undef GNN_PSTAMP
     tile = next_tile;
     next_tile = third_round ? __builtin_amdgcn_readfirstlane(words[8 + pair]) : 0x3fffffff;
     ip_cur = ip_next; src_cur = src_next; w_cur = w_next;

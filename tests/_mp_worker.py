@@ -38,7 +38,7 @@ def main():
             lp.set_state0(s0[rb:rb + nr])
             if layout.startswith('slice'):
                 gr.set_full_adjacency(n, indptr, adj_src, adj_w)
-                lp.set_slice_exchange(int(layout[-1]))
+                lp.set_slice_exchange(True, form='pipelined' if layout[-1] == '1' else 'oneshot')
             k = lp.run()
             k2 = lp.run()                                         # a second Loop on the same communicator
             assert k2 == k

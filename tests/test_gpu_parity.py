@@ -956,3 +956,39 @@ def test_evaluate_runs_the_graphs_side_by_side_with_the_same_results(graph_based
     assert metrics['It'] == int(np.mean(np.asarray([o[0] for o in one_by_one], np.float32)))
     assert abs(metrics['Loss'] - float(np.mean(np.asarray([o[1] for o in one_by_one], np.float32)))) < 1e-6
     assert all(getattr(lp, '_fresh', None) is None for b in batches for (_, lp) in b.device_graph(gnn.device).__dict__.get('_loops', {}).values())
+
+
+@pytest.mark.parametrize('n,hidden,act,nl,max_it,thr', [(4096, (128, 128), 'selu', 3, 6, 0.0), (333, (128, 128), 'tanh', 3, 5, 0.0), (1000, (128,), 'selu', 3, 4, 0.0),
+                                                     (40_000, (128, 128), 'relu', 5, 8, 0.001), (100_003, (128, 128), 'selu', 3, 12, 0.01),
+                                                     (65_552, (128,), 'sigmoid', 3, 3, 0.0), (17, (128, 128), 'selu', 3, 3, 0.0)])
+def test_tile_forms_of_the_default_path_are_bit_identical(n, hidden, act, nl, max_it, thr):
+    """gnn_loop_set_tile_form: one wave per 32-node tile (k_fused) and a wave pair per tile (k_fused_pair: each wave gathers 16 nodes and
+    produces half of every layer's output features, activations cross as bf16 pieces through LDS) evaluate the same arithmetic per node
+    (reference GNN/GNN.py:223-242): k, states and outputs identical bit for bit - full tiles, a partial last tile (333, 1000, 100,003),
+    a range shorter than one side of a tile (17), two- and three-layer nets, wider label blocks (NL 5: concat 139 + hole)."""
+    from GNN import GNN_utils as utils
+    e = _engine()
+    s = utils.syntheticGraph(n, 10.0 if n > 100 else 3.0, nl, 1, 2, seed=n)
+    n = s['n_nodes']
+    rng = np.random.default_rng(n)
+    st = make_mlp(rng, 1 + 2 * (nl + 64), list(hidden) + [64], act, gain=0.6 if thr else 1.0, bn_random=True)
+    ou = make_mlp(rng, nl + 64, [2], 'softmax', bn_random=True)
+    s0 = (0.1 * rng.standard_normal((n, 64))).astype(np.float32)
+    graph = e.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8))
+    mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
+    res = {}
+    for form in (1, 2):
+        lp = e.Loop(graph, mst, mou, 64, max_it, thr)
+        assert lp.set_impl(2) == 2
+        assert lp.set_tile_form(form) == form
+        lp.set_state0(s0)
+        k = lp.run()
+        res[form] = (k, lp.state(), lp.output(), lp.gate_info()[0])
+        assert lp.run() == k                     # and again on the same handle
+        assert np.array_equal(lp.state(), res[form][1])
+        lp.close()
+    graph.close()
+    (k1, s1, o1, r1), (k2, s2, o2, r2) = res[1], res[2]
+    assert k1 == k2 and r1 == r2
+    assert not np.isnan(s2).any()
+    assert np.array_equal(s1, s2) and np.array_equal(o1, o2), f'{int(np.sum(s1 != s2))} of {s1.size} state values differ'

@@ -331,7 +331,7 @@ def test_loopback_group_errors():
     assert e.Loop.run_group(loops) == corc.loop_node(g, st, ou, 4, 5, 0.01, s0)[0]
 
 
-@pytest.mark.parametrize('form', [1, 2])
+@pytest.mark.parametrize('form', ['pipelined', 'oneshot'])
 @pytest.mark.parametrize('world', [2, 4, 8])
 @pytest.mark.parametrize('n,d,hidden', [(1000, 8, (16,)), (4099, 64, (128, 128)), (333, 16, (7,))])
 def test_feature_sliced_exchange_bit_exact(n, d, hidden, world, form):
@@ -339,8 +339,8 @@ def test_feature_sliced_exchange_bit_exact(n, d, hidden, world, form):
     (two all-to-all steps per iteration instead of the all-gather of rows).  The fmaf chain of an aggregated element is the
     same CSR-ordered chain as in the replicated layouts: impl 0 / 1 bit-identical to the C oracle, impl 2 within the tolerance
     of the unsharded run; n = 333 on 8 ranks: the last ranks own nothing, n = 4099: short last shard, partial tiles.
-    form 1 (default): the slice is aggregated in one row block per destination rank and each block is sent on a second stream while
-    the next one is aggregated; form 2: whole slice, then one grouped all-to-all.  Same bits."""
+    'pipelined': the slice is aggregated in one row block per destination rank and each block is sent on a second stream while
+    the next one is aggregated; 'oneshot' (the default of set_slice_exchange(True)): whole slice, then one grouped all-to-all.  Same bits."""
     e = _engine()
     g, st, ou, s0 = _case(300 + n + world, n, d, hidden=hidden)
     indptr, adj_src, adj_w, _, _ = _csr_parts(g)
@@ -350,7 +350,7 @@ def test_feature_sliced_exchange_bit_exact(n, d, hidden, world, form):
         comms, graphs, loops, ranges = _sharded_loops(e, g, st, ou, d, 30, 0.01, s0, world, impl)
         for gr, lp in zip(graphs, loops):
             gr.set_full_adjacency(n, indptr, adj_src, adj_w)
-            lp.set_slice_exchange(form)
+            lp.set_slice_exchange(True, form=form)
         return comms, graphs, loops, ranges
 
     for impl in (1, 0):
@@ -412,7 +412,7 @@ def test_sharded_loop_random_shapes():
             if form.startswith('slice'):
                 for gr, lp in zip(graphs, loops):
                     gr.set_full_adjacency(n, indptr, adj_src, adj_w)
-                    lp.set_slice_exchange(int(form[-1]))
+                    lp.set_slice_exchange(True, form='pipelined' if form[-1] == '1' else 'oneshot')
             k = e.Loop.run_group(loops)
             state, out = _collect(loops, ranges, None)
             tag = (case, world, form, d, nl, hidden, n, impl, max_it, thr)

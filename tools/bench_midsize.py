@@ -21,16 +21,18 @@ def main():
     st = bench.make_net(rng, al + 2 * (nl + d), [128, 128, d], 'selu')
     ou = bench.make_net(rng, nl + d, [t], 'softmax')
     mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
-    print(f'# GNN_FUSED_TILE16={os.environ.get("GNN_FUSED_TILE16", "(auto)")} library={os.path.basename(e.LIB_PATH)}')
+    print(f'# GNN_FUSED_TILE16={os.environ.get("GNN_FUSED_TILE16", "(auto)")} GNN_TILE_FORM={os.environ.get("GNN_TILE_FORM", "0")} library={os.path.basename(e.LIB_PATH)}')
     for n in sizes:
         s = utils.syntheticGraph(n, 10.0, nl, al, t, seed=20261003)
         n = s['n_nodes']
         s0 = (0.1 * np.random.default_rng(1).standard_normal((n, d))).astype(np.float32)
         graph = e.Graph(n, s['indptr'], s['adj_src'], s['adj_w'], s['arc_w'], s['arc_labels_csr'], s['nodes'], np.ones(n, np.uint8))
         res = {}
+        form = int(os.environ.get('GNN_TILE_FORM', '0'))      # default path: 1 one wave per tile, 2 wave pair per tile, 0 library's choice
         for impl in (2, 1):
             loop = e.Loop(graph, mst, mou, d, 30, 0.0)
             loop.set_impl(impl)
+            if impl == 2: loop.set_tile_form(form)
             loop.set_state0(s0)
             loop.run()
             loop.set_profiling(True)

@@ -34,7 +34,7 @@ for r in range(world):
     lp.set_state0(state0[rb:rb + nr])
     if layout == 'slice':
         gr.set_full_adjacency(n, s['indptr'], s['adj_src'], s['adj_w'])
-        lp.set_slice_exchange(int(os.environ.get('SLICE_FORM', 1)))      # 1: return all-to-all block by block beside the aggregation; 2: whole slice, then all-to-all
+        lp.set_slice_exchange(True, form='pipelined' if int(os.environ.get('SLICE_FORM', 1)) == 1 else 'oneshot')      # 1: return all-to-all block by block beside the aggregation; 2: whole slice, then all-to-all
     loops.append(lp); graphs.append(gr)
 e.Loop.run_group(loops)
 t = time.perf_counter()
