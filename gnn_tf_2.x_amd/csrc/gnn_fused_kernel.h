@@ -55,8 +55,12 @@ __device__ __forceinline__ v4f gload4(const float *p) { return *(const GNN_GLOBA
 #ifndef GNN_NT_STREAM
 #define GNN_NT_STREAM 0
 #endif
+// Cache policy of the new-state row stores: 0 default, 2 nt, 16 sc1, 1 sc0 (bits of the buffer instructions' aux operand).  Round 5
+// (profiles/r05_ab_store_policy.txt, BASELINE size, ms per launch): default 0.681, nt 0.666, sc1 0.678, sc0 sc1 0.679, nt sc1 0.664, sc0 nt 0.661,
+// all three 0.663 - every variant with nt gains 2 - 3 %: the rows written for the NEXT iteration no longer displace the table the gather of
+// THIS iteration re-reads ten times.  (The once-read CSR ids / weights as nt loads: +1 %, GNN_NT_STREAM stays 0.)
 #ifndef GNN_STORE_AUX
-#define GNN_STORE_AUX 0       // cache-policy bits of the new-state row stores: 0 default, 2 nt, 16 sc1, 1 sc0 (combinations: A/B of round 5)
+#define GNN_STORE_AUX 2
 #endif
 // 16 bytes of a new-state row at base (wave-uniform) + off floats (per lane)
 __device__ __forceinline__ void gstore_row4(float *base, int64_t off, v4f v)
@@ -68,6 +72,14 @@ __device__ __forceinline__ void gstore_row4(float *base, int64_t off, v4f v)
 #else
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_, v), rs, (int)(off * 4), 0, GNN_STORE_AUX);
+#endif
+}
+__device__ __forceinline__ void gstore_row1(float *p, float v)       // one float of a new-state row (exact path: lane = feature)
+{
+#if GNN_STORE_AUX & 2
+    __builtin_nontemporal_store(v, gptr_w(p));
+#else
+    *gptr_w(p) = v;
 #endif
 }
 __device__ __forceinline__ float gstream1(const float *p)
@@ -1135,7 +1147,7 @@ __device__ __forceinline__ void check_store_fast64(const GnnFusedArgs &a, float 
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = xs[(i + u) * KP];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gptr_w(dst)[(i + u) * Ds] = v[u];
+        for (int u = 0; u < 8; ++u) gstore_row1(dst + (i + u) * Ds, v[u]);
     }
 }
 

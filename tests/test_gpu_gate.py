@@ -40,12 +40,13 @@ def test_certified_gate_on_deep_stops_of_non_contractive_maps():
             cands, run_min = [], min(r[:15])
             for b in range(15, depth):
                 if r[b] < run_min:
-                    cands += [(b, r[b] * 1.02), (b, float(np.sqrt(r[b] * run_min)))]
+                    if r[b] * 1.02 < 0.99 * run_min: cands.append((b, r[b] * 1.02))
+                    if r[b] < 0.9 * run_min: cands.append((b, float(np.sqrt(r[b] * run_min))))
                     run_min = r[b]
             for b, thr in cands[:4]:
                 k1, s1, _ = gs.run(graph, mst, mou, d, depth, thr, s0, 1)
                 k2, s2, rep = gs.run(graph, mst, mou, d, depth, thr, s0, 2)
-                assert k1 == b, (gain, act, seed, b, thr, k1)           # the threshold does what it was picked for
+                assert k1 == b, (gain, act, seed, b, thr, k1, r[max(0, b - 2):b + 1])      # the threshold does what it was picked for
                 if rep:
                     assert np.array_equal(s2, s1)                      # a repeated Loop returns the exact path's bits
                     s2 = gs.run(graph, mst, mou, d, k1, 0.0, s0, 2)[1]

@@ -81,8 +81,8 @@ def study_a(n_seeds, n=100_000, d=64, depth=30):
             run_min = min(r[:15])
             for b in range(15, depth):
                 if r[b] < run_min:
-                    cands.append((b, 'x', r[b] * 1.02))
-                    cands.append((b, 'g', float(np.sqrt(r[b] * run_min))))
+                    if r[b] * 1.02 < 0.99 * run_min: cands.append((b, 'x', r[b] * 1.02))
+                    if r[b] < 0.9 * run_min: cands.append((b, 'g', float(np.sqrt(r[b] * run_min))))
                     run_min = r[b]
             if not cands:
                 print(f'{gain} {act} {seed} | no new minimum of the max ratio in bodies 15..{depth - 1} (min of the first 15: {min(r[:15]):.3g}, last: {r[-1]:.3g})')
