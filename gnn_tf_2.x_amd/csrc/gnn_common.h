@@ -229,8 +229,6 @@ struct gnn_mlp {
     size_t packed_floats = 0;
     int *packed_split = nullptr;        // bf16-piece weight image of the split-arithmetic fused kernel (impl 2)
     size_t packed_split_dwords = 0;
-    int *packed_split16 = nullptr;      // the same pieces in the operand order of the 16-node-tile kernel (gnn_fused16_kernel.h), or nullptr
-    size_t packed_split16_dwords = 0;
     int pack_nlc = -1;                  // node-label columns of the concat the split image was laid out for (alignment hole)
     bool pack_dirty = true;             // the images are rebuilt on the next fused use (training rewrites the weights every step)
     uint64_t version = 0;

@@ -6,7 +6,6 @@
 constexpr int GNN_FUSED_MAXL = 3;
 constexpr int GNN_FUSED_WAVES = 8;                 // waves per (persistent) workgroup; w and w + 4 share a SIMD
 constexpr int GNN_FUSED_THREADS = 64 * GNN_FUSED_WAVES;
-constexpr int GNN_FUSED16_WAVES = 12;              // 16-node-tile kernel (gnn_fused16_kernel.h): 3 waves per SIMD
 
 struct GnnFusedArgs {
     // graph
@@ -105,12 +104,5 @@ bool gnn_fused_launch_s3(int act, int nt, int ntl, const GnnFusedArgs &a, unsign
 // wave-pair form (gnn_fused_pair_kernel.h: split arithmetic, state width 64, 128-wide hidden layers, 9 layer-0 chunks): gnn_fused_p{2,3}.hip
 bool gnn_fused_launch_p2(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_p3(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
-// 16-node-tile kernel (split arithmetic, state width 64), 2 / 3 layers; nf: 16-feature tiles of the hidden layers (4 or 8)
-bool gnn_fused_launch_h2(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
-bool gnn_fused_launch_h3(int act, int nf, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
-// 64-node tiles on one wave per SIMD (gnn_fused64_kernel.h; split arithmetic, state width 64, 128-wide hidden layers): gnn_fused_w{2,3}.hip
-// EXPERIMENT, diagnostic build only (experiments/gnn_fused64_kernel.h): 64-node tiles on one wave per SIMD - measured slower than k_fused
-bool gnn_fused_launch_w2(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
-bool gnn_fused_launch_w3(int act, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l2(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);
 bool gnn_fused_launch_l3(int act, int nt, int ntl, const GnnFusedArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st);

@@ -28,9 +28,6 @@ struct FusedPlan {
     // split arithmetic (impl 2): K = 16 chunks per layer and the dword offsets of the bf16-piece images
     int chunks[MAXL] = {0, 0, 0};
     size_t s_off[MAXL] = {0, 0, 0}, s_total = 0;
-    // 16-node-tile kernel (gnn_fused16_kernel.h): K = 32 chunks, 16-feature output tiles; dword offsets of its bf16-piece image
-    int chunks16[MAXL] = {0, 0, 0}, nf16[MAXL] = {0, 0, 0};
-    size_t s16_off[MAXL] = {0, 0, 0}, s16_total = 0;
 };
 
 constexpr int GNN_FUSED_VARIANT_DEFAULT = 1;      // bit 0: raised wave priority during the gather (measured: -1 %)
@@ -88,19 +85,8 @@ bool make_plan(const gnn_mlp *m, int nlc, FusedPlan &p)
         soff += (size_t)(p.chunks[l] + (l == 0 ? S_SLACK : 0)) * p.nt[l] * 3 * 256;
     }
     p.s_total = soff;
-    soff = 0;
-    for (int l = 0; l < p.layers; ++l) {
-        p.nf16[l] = 2 * p.nt[l];
-        p.chunks16[l] = l == 0 ? 5 : p.NT;           // layer 0: always GNN_F16_CH0 = 5 chunks (K = 160, zero beyond the concat); hidden: 32 NT input features
-        p.s16_off[l] = soff;
-        soff += (size_t)p.chunks16[l] * p.nf16[l] * 3 * 256;
-    }
-    p.s16_total = soff;
     return true;
 }
-
-// the 16-node-tile kernel covers the tuned shape only: state width 64, two or three layers, hidden width 64 or 128, split arithmetic
-bool tile16_covers(const FusedPlan &p, int ds) { return ds == 64 && p.NTL == 2 && p.layers >= 2 && (p.NT == 2 || p.NT == 4); }
 
 // GNN_FUSED_WAVES wave tiles [32][KP], 128 B of slack (the layer-0 pipeline reads two groups past the last tile), GNN_FUSED_WAVES x 36 row pointers
 size_t lds_bytes(const FusedPlan &p)
@@ -124,17 +110,30 @@ size_t pair_lds_bytes(const FusedPlan &p)
 {
     return sizeof(float) * ((size_t)4 * (32 * pair_xs(p) + p.chunks[0] * 768) + 16 + GNN_FUSED_WAVES * 20 + 3 * 32 * 2 + 2 * 32 * 4) + 128;
 }
-// the library's choice between the two forms of the default path's kernel (gnn_loop_set_tile_form(l, 0)); DESIGN.md 4.1 has the measurements
-constexpr int GNN_TILE_FORM_DEFAULT = 1;
+int device_cus(int device)
+{
+    static int n_cu_dev[64] = {0};
+    if (device < 0 || device >= 64) return 256;
+    if (!n_cu_dev[device]) {
+        hipDeviceProp_t prop;
+        n_cu_dev[device] = hipGetDeviceProperties(&prop, device) == hipSuccess ? std::max(1, prop.multiProcessorCount) : 256;
+    }
+    return n_cu_dev[device];
+}
 
 }   // namespace
 
+// The library's choice between the two forms of the default path's kernel (gnn_loop_set_tile_form(l, 0)): the wave pair while no pair of the
+// launch gets a second tile (tiles <= 4 x CUs: the launch is one tile latency long and a pair's tile takes about half as long as a wave's:
+// N = 4 k .. 32 k: 7 - 11 % less time per iteration), one wave per tile beyond (N = 41 k: +13 %, BASELINE size: 0.78 against 0.68 ms -
+// the seven meetings of a pair per tile cost more than its shorter matrix phases return; profiles/r05_midsize_forms.txt, r05_pair_stamps.txt).
 bool gnn_fused_pair_selected(const gnn_loop *l)
 {
     FusedPlan p;
     if (l->impl_req != 2 || l->slice_mode || !make_plan(l->st, l->NLc, p)) return false;
-    const int form = l->tile_form ? l->tile_form : GNN_TILE_FORM_DEFAULT;
-    return form == 2 && pair_covers(p, l->Ds) && pair_lds_bytes(p) <= 160 * 1024;
+    if (!pair_covers(p, l->Ds) || pair_lds_bytes(p) > 160 * 1024) return false;
+    if (l->tile_form) return l->tile_form == 2;
+    return (l->g->n_rows + 31) / 32 <= (int64_t)4 * device_cus(l->device);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -148,12 +147,6 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
     const int lab = m->dims.back() + nlc;      // [state | nodes] columns in front of the alignment hole
     std::vector<float> img(p.total, 0.0f);
     std::vector<uint32_t> simg(p.s_total, 0u);
-#ifdef GNN_DIAG      // the 16-node-tile kernel (experiments/gnn_fused16_kernel.h: measured slower at every size, round 3) only exists in the diagnostic build
-    const bool want16 = tile16_covers(p, m->dims.back());
-#else
-    const bool want16 = false;
-#endif
-    std::vector<uint32_t> simg16(want16 ? p.s16_total : 0, 0u);
     std::vector<float> W, b;
     for (int l = 0; l < m->n_layers; ++l) {
         const int n_in = m->dims[l], n_out = m->dims[l + 1];
@@ -201,33 +194,6 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
                             d |= (i & 1) ? hi : (hi >> 16);
                         }
                     }
-        // image of the 16-node-tile kernel: [K = 32 chunk][16-feature out tile][piece][lane][8 bf16]; lane = (row f & 15, k group g),
-        // element i of the lane is k slot (g, i) of gnn_fused16_kernel.h; same folding factors
-        if (want16) {
-            uint32_t *sp16 = simg16.data() + p.s16_off[l];
-            const int nf = p.nf16[l];
-            for (int c = 0; c < p.chunks16[l]; ++c)
-                for (int ft = 0; ft < nf; ++ft)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int i = 0; i < 8; ++i) {
-                            const int g = lane >> 4;
-                            int k = l == 0 ? 32 * c + 8 * g + i : 32 * c + 16 * (i >> 2) + 4 * g + (i & 3);
-                            if (l == 0 && p.pad) k = k < lab ? k : (k < lab + p.pad ? n_in : k - p.pad);       // LDS column -> concat column (hole: zero)
-                            const int j = 16 * ft + (lane & 15);
-                            float v = (k < n_in && j < n_out) ? W[(size_t)k * n_out + j] : 0.0f;
-                            v *= fold;
-                            for (int pc = 0; pc < 3; ++pc) {
-                                uint32_t bits;
-                                memcpy(&bits, &v, 4);
-                                const uint32_t hi = bits & 0xffff0000u;
-                                float piece;
-                                memcpy(&piece, &hi, 4);
-                                v = v - piece;
-                                uint32_t &d = sp16[((((size_t)c * nf + ft) * 3 + pc) * 64 + lane) * 4 + i / 2];
-                                d |= (i & 1) ? hi : (hi >> 16);
-                            }
-                        }
-        }
     }
     if (m->has_bn) {
         const int f = m->dims.back();
@@ -247,14 +213,6 @@ int gnn_fused_pack(gnn_mlp *m, int nlc)
         m->packed_split_dwords = p.s_total;
     }
     HIPCHK(hipMemcpy(m->packed_split, simg.data(), p.s_total * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (m->packed_split16_dwords != simg16.size()) {
-        if (m->packed_split16) (void)hipFree(m->packed_split16);
-        m->packed_split16 = nullptr;
-        m->packed_split16_dwords = 0;
-        if (!simg16.empty()) HIPCHK(gnn_dev_malloc((void **)&m->packed_split16, simg16.size() * sizeof(uint32_t)));
-        m->packed_split16_dwords = simg16.size();
-    }
-    if (!simg16.empty()) HIPCHK(hipMemcpy(m->packed_split16, simg16.data(), simg16.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return GNN_OK;
 }
 
@@ -262,13 +220,10 @@ void gnn_fused_release(gnn_mlp *m)
 {
     if (m->packed) (void)hipFree(m->packed);
     if (m->packed_split) (void)hipFree(m->packed_split);
-    if (m->packed_split16) (void)hipFree(m->packed_split16);
     m->packed = nullptr;
     m->packed_split = nullptr;
-    m->packed_split16 = nullptr;
     m->packed_floats = 0;
     m->packed_split_dwords = 0;
-    m->packed_split16_dwords = 0;
 }
 
 bool gnn_fused_supported(const gnn_loop *l)
@@ -314,8 +269,6 @@ int gnn_fused_prepare(gnn_loop *l)
     }
     return GNN_OK;
 }
-
-static inline bool m_has16(const gnn_mlp *m) { return m->packed_split16 != nullptr; }
 
 // everything of the kernel arguments that does not depend on the launch geometry; split: arithmetic mode / tile layout
 static int fused_args(gnn_loop *l, int k, bool split, FusedPlan &p, GnnFusedArgs &a)
@@ -390,14 +343,8 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         a.stamps = stamp_buf;
     }
 #endif
-    static int n_cu_dev[64] = {0};
     if (l->device < 0 || l->device >= 64) return gnn_fail(GNN_ERR_ARG, "device %d out of range", l->device);
-    if (!n_cu_dev[l->device]) {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, l->device));
-        n_cu_dev[l->device] = std::max(1, prop.multiProcessorCount);
-    }
-    const int n_cu = n_cu_dev[l->device];
+    const int n_cu = device_cus(l->device);
     // one workgroup per CU; small graphs spread their tiles over as many CUs as they have tiles (a tile alone on a CU runs
     // faster than eight sharing its L1 / LDS / SIMDs; the waves without a tile leave at once)
     const unsigned grid = (unsigned)std::min<size_t>((size_t)n_cu, n_tiles);
@@ -434,32 +381,8 @@ int gnn_fused_iteration(gnn_loop *l, int k)
     };
     bool ok = false;
     const int64_t n_tiles64 = (g->n_rows + 31) / 32;
-    // EXPERIMENT of round 4 (diagnostic build, GNN_FUSED_WIDE=1): 64-node tiles on one wave per SIMD, every weight fragment feeding two 32-node
-    // halves, the next tile's gather inside the current tile's matrix phase through an LDS-DMA ring (experiments/gnn_fused64_kernel.h).
-    // Bit-identical to this kernel and slower: 0.97 ms against 0.70 ms per launch at BASELINE size (profiles/r04_fused64_stamps.txt) -
-    // vector-memory results return in order, so the weight fragments requested behind a gather batch wait for its HBM-latency rows.
-    bool wide = false;
-#ifdef GNN_DIAG
-    {
-        static const int wide_env = getenv("GNN_FUSED_WIDE") ? atoi(getenv("GNN_FUSED_WIDE")) : 0;
-        const int64_t n_tiles_w = g->n_rows / 64;
-        const bool want = wide_env && split && !a.agg_in && l->Ds == 64 && p.NTL == 2 && p.NT == 4 && (p.layers == 2 || p.layers == 3) && g->n_rows % 64 == 0 && n_tiles_w >= 1;
-        if (want) {
-            GnnFusedArgs aw = a;
-            const int waves = 4;
-            aw.full_tiles = 1; aw.tile_base = 0;
-            const unsigned grid_w = (unsigned)std::min<int64_t>((int64_t)n_cu, (n_tiles_w + waves - 1) / waves);
-            aw.single_ticket = n_tiles_w <= (int64_t)waves * grid_w ? 1 : 0;
-            aw.stagger = n_tiles_w >= (int64_t)4 * waves * grid_w ? stagger_rounds : 0;
-            const size_t lds_w = (size_t)waves * (64 * (size_t)(aw.KP - 64) + 4096) * sizeof(float) + 128 + (size_t)waves * 68 * sizeof(int) + (3 + 2) * 32 * 4 * sizeof(float) + 16;
-            aw.lds_floats = gnn_poison_enabled() ? (int)(lds_w / sizeof(float)) : 0;
-            if (lds_w <= 160 * 1024)
-                wide = p.layers == 2 ? gnn_fused_launch_w2(p.act, aw, grid_w, lds_w, l->stream) : gnn_fused_launch_w3(p.act, aw, grid_w, lds_w, l->stream);
-        }
-    }
-#endif
     bool pair = false;
-    if (!wide && split && gnn_fused_pair_selected(l)) {
+    if (split && gnn_fused_pair_selected(l)) {
         // wave-pair form: four pairs per workgroup, one workgroup per CU; the tile counters, gates and flags are k_fused's
         GnnFusedArgs ap = a;
         ap.KP = pair_xs(p);
@@ -470,29 +393,8 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         ap.lds_floats = gnn_poison_enabled() ? (int)(lds_p / sizeof(float)) : 0;
         pair = p.layers == 2 ? gnn_fused_launch_p2(p.act, ap, grid_p, lds_p, l->stream) : gnn_fused_launch_p3(p.act, ap, grid_p, lds_p, l->stream);
     }
-    if (wide || pair) ok = true;
-    else {
-    // Experiment of round 3 (diagnostic build, GNN_FUSED_TILE16=1): 16-node tiles on v_mfma_f32_16x16x32_bf16, three waves per SIMD
-    // (experiments/gnn_fused16_kernel.h).  Correct, and slower than this kernel at every size from 31 k to 500 k nodes:
-    // every wave streams the weight image per 16 instead of 32 nodes and the vector L1 fill rate (64 B / clk / CU) becomes the bound.
-#ifdef GNN_DIAG
-    static const int tile16_env = getenv("GNN_FUSED_TILE16") ? atoi(getenv("GNN_FUSED_TILE16")) : 0;
-    const bool use16 = tile16_env && split && !a.agg_in && m_has16(l->st) && tile16_covers(p, l->Ds);
-    if (use16) {
-        GnnFusedArgs h = a;
-        const gnn_mlp *m = l->st;
-        h.Ws_base = m->packed_split16;
-        h.ws_bytes = (int)(p.s16_total * sizeof(uint32_t));
-        for (int i = 0; i < p.layers; ++i) h.ws_off[i] = (int)(p.s16_off[i] * sizeof(uint32_t));
-        h.chunks0 = p.chunks16[0];
-        const int64_t n_tiles16 = (g->n_rows + 15) / 16;
-        const unsigned grid16 = (unsigned)std::min<int64_t>((int64_t)n_cu, (n_tiles16 + GNN_FUSED16_WAVES - 1) / GNN_FUSED16_WAVES);
-        h.stagger = 0;
-        const size_t lds16 = (size_t)GNN_FUSED16_WAVES * 16 * h.KP * sizeof(float) + 128 + GNN_FUSED16_WAVES * 20 * sizeof(int) + (192 + 2 * 128) * sizeof(float) + 16;
-        ok = p.layers == 2 ? gnn_fused_launch_h2(p.act, p.nf16[0], h, grid16, lds16, l->stream) : gnn_fused_launch_h3(p.act, p.nf16[0], h, grid16, lds16, l->stream);
-    } else
-#endif
-    if (l->Ds == 64 && p.NTL == 2 && n_tiles64 >= 1) {
+    if (pair) ok = true;
+    else if (l->Ds == 64 && p.NTL == 2 && n_tiles64 >= 1) {
         // the full-tile specialisation (no generic paths compiled in) on every tile; a partial last tile takes a wave-uniform
         // branch with masked row stores / condition votes (the row buffers are padded to whole tiles, rows past n_rows have no arcs)
         GnnFusedArgs af = a;
@@ -500,7 +402,6 @@ int gnn_fused_iteration(gnn_loop *l, int k)
         ok = go(af, (unsigned)std::min<size_t>((size_t)n_cu, (size_t)n_tiles64));
     } else
         ok = go(a, grid);
-    }
     if (!ok) return gnn_fail(GNN_ERR_UNSUPPORTED, "no fused instantiation for %d layers, tiles (%d,%d), activation %d", p.layers, p.NT, p.NTL, p.act);
 #ifdef GNN_DIAG
     if (a.stamps) {

@@ -207,6 +207,12 @@ __global__ void __launch_bounds__(GNN_FUSED_THREADS, 2) k_fused_pair(const GnnFu
     const GnnFusedArgs &a = a0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!gnn_gate_open(a.gate, a.world)) return;
+#ifdef GNN_DIAG      // GNN_POISON=1: NaN over the whole LDS allocation before anything is staged (a read of a never-written word shows as a NaN)
+    if (a.lds_floats) {
+        for (int t = threadIdx.x; t < a.lds_floats; t += blockDim.x) lds[t] = __builtin_nanf("");
+        __syncthreads();
+    }
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int px = (a.variant & 512) ? 4 : 1;                     // partner on another SIMD (default) or the SIMD's other wave (experiment)
     const int partner = wave ^ px;
