@@ -84,20 +84,6 @@ hipError_t gnn_dev_malloc(void **p, size_t bytes)
     return e;
 }
 
-// EXPERIMENT (round 5, GNN_UNCACHED_CSR=1): the once-per-iteration streams (CSR ids / weights) in memory the caches do not keep
-// (hipDeviceMallocUncached), so that they do not displace the state table from L2 / Infinity Cache
-template <typename T>
-static int dev_upload_stream(T **p, const T *host, size_t count)
-{
-    static const bool uncached = getenv("GNN_UNCACHED_CSR") && atoi(getenv("GNN_UNCACHED_CSR")) != 0;
-    *p = nullptr;
-    if (count == 0) count = 1;
-    if (uncached) HIPCHK(hipExtMallocWithFlags((void **)p, count * sizeof(T), hipDeviceMallocUncached));
-    else HIPCHK(gnn_dev_malloc((void **)p, count * sizeof(T)));
-    HIPCHK(hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
-    return GNN_OK;
-}
-
 template <typename T>
 static int dev_alloc(T **p, size_t count)
 {
@@ -759,8 +745,8 @@ static int graph_create_impl(int64_t n_index, int64_t n_global, int64_t row_begi
     std::vector<int32_t> both(rows);
     both.insert(both.end(), pos.begin(), pos.end());
     int rc = 0;
-    if ((rc = dev_upload(&g->sh->indptr, indptr, (size_t)n_rows + 1)) || (rc = dev_upload_stream(&g->sh->adj_src, adj_src, (size_t)n_arcs)) ||
-        (rc = dev_upload_stream(&g->sh->adj_w, adj_w, (size_t)n_arcs)) || (rc = dev_upload(&g->sh->arc_w, arc_w, (size_t)n_arcs)) ||
+    if ((rc = dev_upload(&g->sh->indptr, indptr, (size_t)n_rows + 1)) || (rc = dev_upload(&g->sh->adj_src, adj_src, (size_t)n_arcs)) ||
+        (rc = dev_upload(&g->sh->adj_w, adj_w, (size_t)n_arcs)) || (rc = dev_upload(&g->sh->arc_w, arc_w, (size_t)n_arcs)) ||
         (rc = dev_upload(&g->sh->arc_labels, arc_labels, (size_t)n_arcs * dim_arc_label)) ||
         (rc = dev_upload(&g->sh->mask, mask, (size_t)n_rows)) || (rc = dev_upload(&g->sh->masked_rows, both.data(), both.size())) ||
         (rc = dev_upload(&g->nodes, nodes, (size_t)n_index * dim_node_label))) {
