@@ -1211,6 +1211,207 @@ int launch_fwd3(hipStream_t st, BufT &buf, const gnn_mlp *m, int64_t n, const fl
     return GNN_OK;
 }
 
+// The backward chain of the same 3-layer net in ONE pass over the rows (round 5): d z2 (the gradient at the last layer's pre-activation) ->
+//     d z1 = (d z2 . W2^T) * act'(a1)  ->  d z0 = (d z1 . W1^T) * act'(a0)  ->  d inp = d z0 . W0^T
+// with the chain of the fused kernels - the first product from the wave's LDS tile, the following ones from the previous accumulators without
+// leaving registers (layer_split_from_regs with the identity in place of the activation) - and d z1, d z0 (operands of the weight gradients)
+// and d inp written out on the way, each through the LDS tile as whole row pieces.  The stored activations a1 / a0 pass through the same tile
+// (coalesced rows in, accumulator layout out).  Replaces three k_gemm_split passes (+ the narrow fourth for columns >= 128 of d inp): d z1 and
+// d z0 are no longer re-read and re-staged (2 x 512 MB at 1 M rows), one launch instead of four.
+struct Bwd3Args {
+    int64_t n;
+    int K0, w1, w2, w3, KP, chunksA, act;
+    int img_bytes, offB, offC, offD;         // one packed image: W2^T (from LDS, 4 tiles) | W1^T (from registers, 4 tiles) | W0^T columns [0, 128) | [128, K0)
+    const float *DZ2, *A1, *A0;
+    const uint32_t *img;
+    float *DZ1, *DZ0, *DINP;
+};
+
+__global__ void __launch_bounds__(64 * TG_WAVES, 2) k_bwd3_split(const Bwd3Args p)
+{
+    using namespace gnn_fused_dev;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = p.KP;
+    float *X = lds + (size_t)wave * 32 * KP;
+    float *zb = lds + (size_t)TG_WAVES * 32 * KP + 32;                   // [128] zeros: the accumulators start from it (no bias in a backward product)
+    for (int t = threadIdx.x; t < 128; t += blockDim.x) zb[t] = 0.0f;
+    __syncthreads();
+    const int64_t n_tiles = (p.n + 31) / 32, stride = (int64_t)gridDim.x * TG_WAVES;
+    const int half = lane >> 5, node = lane & 31;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.img), 0, p.img_bytes, 0x00020000);
+    // 32 rows of a dense [n, width] array (width a multiple of 4, <= 128) into the tile as [row][column]: all pieces requested before the first is
+    // written (one round trip, covered by the SIMD's other wave); columns [width, zero_to) are zeroed
+    auto stage_rows = [&](const float *src_all, int width, int zero_to, int nvalid, int64_t i0) {
+        constexpr int MAXQ = 16;                                         // 32 x 128 floats = 16 pieces of 16 bytes per lane
+        v4f nxt[MAXQ];
+        const int total = nvalid * width;
+        const float *src = src_all + i0 * width;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int e = lane * 4 + 256 * q;
+            nxt[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (e < total) nxt[q] = gload4(src + e);
+        }
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const float inv_w = 1.0f / (float)width;
+        if (zero_to > width) {
+            const int zw = zero_to - width;
+            for (int t = lane_o; t < 32 * zw; t += 64) X[(t / zw) * KP + width + t % zw] = 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int e = lane_o * 4 + 256 * q;
+            if (e < 32 * width) {
+                const int r = (int)(((float)e + 0.5f) * inv_w), c = e - r * width;
+                *reinterpret_cast<v4f *>(X + r * KP + c) = nxt[q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    // accumulators (feature on the register, row on the lane) times act'(stored activation), the activations read from the tile in the same layout
+    auto times_act_grad = [&](f32x16 (&h)[4]) {
+        int half_o = half;
+        asm volatile("" : "+v"(half_o));
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f a4 = *reinterpret_cast<const v4f *>(X + node * KP + 32 * jt + 8 * q + 4 * half_o);
+                h[jt][4 * q] *= act_grad(a4.x, p.act); h[jt][4 * q + 1] *= act_grad(a4.y, p.act);
+                h[jt][4 * q + 2] *= act_grad(a4.z, p.act); h[jt][4 * q + 3] *= act_grad(a4.w, p.act);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    // NTT accumulator tiles -> [row][column] in the tile -> whole row pieces to columns [col0, col0 + 32 NTT) of dst [n, width]
+    auto store_rows = [&](auto &h, auto NTc, float *dst, int width, int col0, int nvalid, int64_t i0) {
+        constexpr int NTT = decltype(NTc)::value;
+        int half_o = half;
+        asm volatile("" : "+v"(half_o));
+#pragma unroll
+        for (int jt = 0; jt < NTT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<v4f *>(X + node * KP + 32 * jt + 8 * q + 4 * half_o) = v4f{h[jt][4 * q], h[jt][4 * q + 1], h[jt][4 * q + 2], h[jt][4 * q + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        constexpr int PPR = 8 * NTT;
+        const bool vec = (width & 3) == 0 && (col0 & 3) == 0;
+        int lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+#pragma unroll
+        for (int u = 0; u < 32 * PPR / 64; ++u) {
+            const int idx = lane_p + 64 * u, r = idx / PPR, c = (idx % PPR) * 4;
+            if (r < nvalid && col0 + c < width) {
+                const v4f a4 = *reinterpret_cast<const v4f *>(X + r * KP + c);
+                const int64_t o = (i0 + r) * width + col0 + c;
+                if (vec && col0 + c + 4 <= width) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + o) = a4;
+                else {
+                    const float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                    for (int t = 0; t < 4; ++t) if (col0 + c + t < width) gptr_w(dst)[o + t] = v[t];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    for (int64_t tile = (int64_t)blockIdx.x * TG_WAVES + wave; tile < n_tiles; tile += stride) {
+        const int64_t i0 = tile * 32;
+        const int nvalid = (int)((p.n - i0) < 32 ? (p.n - i0) : 32);
+        f32x16 g[4], acc[4];
+        // d z2 tile -> d h2 = d z2 . W2^T
+        stage_rows(p.DZ2, p.w3, 16 * p.chunksA, nvalid, i0);
+        layer0_split<4, true>(X + node * KP + 8 * half, wrs, lane * 16, 0, p.chunksA, g, zb, half);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        stage_rows(p.A1, p.w2, 128, nvalid, i0);
+        times_act_grad(g);                                               // g = d z1
+        store_rows(g, std::integral_constant<int, 4>{}, p.DZ1, p.w2, 0, nvalid, i0);
+        layer_split_from_regs<4, 4, GNN_ACT_LINEAR>(g, zb, half, acc, wrs, lane * 16, p.offB);
+        stage_rows(p.A0, p.w1, 128, nvalid, i0);
+        times_act_grad(acc);                                             // acc = d z0
+        store_rows(acc, std::integral_constant<int, 4>{}, p.DZ0, p.w1, 0, nvalid, i0);
+        layer_split_from_regs<4, 4, GNN_ACT_LINEAR>(acc, zb, half, g, wrs, lane * 16, p.offC);
+        f32x16 tail[1];
+        if (p.K0 > 128) layer_split_from_regs<4, 1, GNN_ACT_LINEAR>(acc, zb, half, tail, wrs, lane * 16, p.offD);
+        // d inp: all K0 columns into the tile, then the tile's rows as ONE flat run of nvalid x K0 floats - it starts on a 16-byte boundary whatever
+        // K0 is (32 K0 floats per tile), so memory is written in aligned 16-byte pieces even for K0 = 135 (a piece may straddle two tile rows)
+        {
+            int half_o = half;
+            asm volatile("" : "+v"(half_o));
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<v4f *>(X + node * KP + 32 * jt + 8 * q + 4 * half_o) = v4f{g[jt][4 * q], g[jt][4 * q + 1], g[jt][4 * q + 2], g[jt][4 * q + 3]};
+            if (p.K0 > 128) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (128 + 8 * q + 4 * half_o + 4 <= KP)
+                        *reinterpret_cast<v4f *>(X + node * KP + 128 + 8 * q + 4 * half_o) = v4f{tail[0][4 * q], tail[0][4 * q + 1], tail[0][4 * q + 2], tail[0][4 * q + 3]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int K0 = p.K0, total = nvalid * K0;
+            const float inv_k = 1.0f / (float)K0;
+            float *dst = p.DINP + i0 * K0;
+            int lane_p = lane;
+            asm volatile("" : "+v"(lane_p));
+            for (int e = 4 * lane_p; e < total; e += 256) {
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int ee = e + t < total ? e + t : total - 1;
+                    const int r = (int)(((float)ee + 0.5f) * inv_k), c = ee - r * K0;
+                    v[t] = X[r * KP + c];
+                }
+                if (e + 4 <= total) *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(dst) + e) = v4f{v[0], v[1], v[2], v[3]};
+                else
+                    for (int t = 0; t < 4; ++t) if (e + t < total) gptr_w(dst)[e + t] = v[t];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}
+
+inline bool bwd3_covers(const gnn_mlp *m)
+{
+    return fwd3_covers(m) && (m->dims[1] & 3) == 0 && (m->dims[2] & 3) == 0 && (m->dims[3] & 3) == 0 && m->dims[0] <= 160;
+}
+
+// WT[l]: the transposed kernels [n_out, n_in] of the three layers (Net::WT)
+template <class BufT>
+int launch_bwd3(hipStream_t st, BufT &buf, const gnn_mlp *m, float *const *WT, int64_t n, const float *dz2, const float *a1, const float *a0, float *dz1,
+                float *dz0, float *dinp)
+{
+    static bool raised = false;
+    if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bwd3_split), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    Bwd3Args p{};
+    p.n = n; p.K0 = m->dims[0]; p.w1 = m->dims[1]; p.w2 = m->dims[2]; p.w3 = m->dims[3]; p.act = m->acts[0];
+    p.KP = std::max(tg_kps(128), tg_kps(p.K0));
+    p.chunksA = (p.w3 + 15) / 16;
+    const size_t blk = 3 * 256;                                          // dwords per (chunk, tile)
+    const size_t dA = (size_t)(p.chunksA + 2) * 4 * blk, dB = (size_t)8 * 4 * blk, dC = (size_t)8 * 4 * blk, dD = (size_t)8 * 1 * blk;
+    uint32_t *img = nullptr;
+    int rc = buf.get(&img, dA + dB + dC + dD);
+    if (rc) return rc;
+    // W2^T: [K = w3, n_cols = w2] from the tile (plain k order); W1^T: [w2, w1] and W0^T: [w1, K0] from the accumulators (hidden k order)
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)(p.chunksA + 2) * 4 * 256, 256), 256, 0, st, p.w3, p.w2, 0, 4, p.chunksA + 2, WT[2], img, 0, 1.0f);
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)8 * 4 * 256, 256), 256, 0, st, p.w2, p.w1, 0, 4, 8, WT[1], img + dA, 1, 1.0f);
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)8 * 4 * 256, 256), 256, 0, st, p.w1, p.K0, 0, 4, 8, WT[0], img + dA + dB, 1, 1.0f);
+    hipLaunchKernelGGL(k_pack_split, cdiv((int64_t)8 * 1 * 256, 256), 256, 0, st, p.w1, p.K0, 128, 1, 8, WT[0], img + dA + dB + dC, 1, 1.0f);
+    p.img = img; p.img_bytes = (int)((dA + dB + dC + dD) * sizeof(uint32_t));
+    p.offB = (int)(dA * sizeof(uint32_t)); p.offC = (int)((dA + dB) * sizeof(uint32_t)); p.offD = (int)((dA + dB + dC) * sizeof(uint32_t));
+    p.DZ2 = dz2; p.A1 = a1; p.A0 = a0; p.DZ1 = dz1; p.DZ0 = dz0; p.DINP = dinp;
+    const size_t lds = sizeof(float) * ((size_t)TG_WAVES * 32 * p.KP + 32 + 128) + 16;
+    if (lds > 160 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused backward: LDS");
+    const int64_t n_tiles = (n + 31) / 32;
+    const unsigned grid = (unsigned)std::min<int64_t>(256, (n_tiles + TG_WAVES - 1) / TG_WAVES);
+    hipLaunchKernelGGL(k_bwd3_split, grid, 64 * TG_WAVES, lds, st, p);
+    HIPCHK(hipGetLastError());
+    return GNN_OK;
+}
+
 // [dW; db] partials of one row chunk: D[hf, zf] = sum over the chunk's rows of [H | 1][r, hf] d z[r, zf].  Rows are the K dimension of
 // the 32x32x2 MFMA: lane (m, k half) loads H[r0 + 2 kk + k half][32 mt + m] and d z[..][32 nt + m] - whole 128-byte row pieces per
 // half-wave, straight from memory, no staging.  Block = 4 waves, each a quarter of the chunk's rows, MT tiles of [H | 1] columns x up to
@@ -2019,7 +2220,23 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         }
     }
     // d is d loss / d z of layer l at the top of every pass
-    for (int l = L - 1; l >= 0; --l) {
+    // a 3-layer net without Dropout on many rows: the whole chain d z2 -> d z1 -> d z0 -> d inp in one pass (k_bwd3_split), then the three weight gradients
+    bool chain3 = n > 0 && L == 3 && tg_many_rows(n) && bwd3_covers(m) && net.rate[0] == 0.0f && net.rate[1] == 0.0f && net.rate[2] == 0.0f;
+    for (int l = 0; l < 3 && chain3; ++l) chain3 = tg_wide(m->dims[l + 1], m->dims[l]) && tg_wgrad_covers(m->dims[l], m->dims[l + 1]);
+#ifdef GNN_DIAG
+    static const bool chain_off = getenv("GNN_TRAIN_BWD3") && atoi(getenv("GNN_TRAIN_BWD3")) == 0;
+    if (chain_off) chain3 = false;
+#endif
+    if (chain3) {
+        float *dz1 = nullptr, *dz0 = nullptr, *dinp = nullptr;
+        if ((rc = buf.get(&dz1, (size_t)n * m->dims[2])) || (rc = buf.get(&dz0, (size_t)n * m->dims[1])) || (rc = buf.get(&dinp, (size_t)n * m->dims[0]))) return rc;
+        if ((rc = launch_bwd3(st, buf, m, net.WT.data(), n, d, c.a[1], c.a[0], dz1, dz0, dinp))) return rc;
+        const float *dzs[3] = {dz0, dz1, d};
+        for (int l = 2; l >= 0; --l)
+            if ((rc = launch_wgrad_f32(st, n, rpb, parts, ps, m->dims[l], m->dims[l + 1], c.hin[l], dzs[l], net.part + net.g_off[2 * l]))) return rc;
+        d = dinp;
+    }
+    for (int l = chain3 ? -1 : L - 1; l >= 0; --l) {
         const int ni = m->dims[l], no = m->dims[l + 1];
         float *dprev = nullptr;
         if ((rc = buf.get(&dprev, (size_t)n * ni))) return rc;
