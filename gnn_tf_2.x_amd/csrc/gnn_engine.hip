@@ -158,7 +158,7 @@ int gnn_graph_wait_ready(const gnn_graph *g, hipStream_t st)
 
 // out[r, :] = sum over the stored entries e of row r, in order, of w[e] * X[src(e), :]     (fmaf chain)
 // lpr lanes (power of two <= 64) cooperate on a row, each owning VEC consecutive columns per chunk.
-template <int VEC, bool INDEXED>
+template <int VEC, bool INDEXED, int U = 4>
 __global__ void __launch_bounds__(256) k_spmm(int64_t n_rows, const int32_t *__restrict__ indptr,
                                               const int32_t *__restrict__ idx, const float *__restrict__ w,
                                               const float *__restrict__ X, int width, int64_t ldx,
@@ -174,33 +174,61 @@ __global__ void __launch_bounds__(256) k_spmm(int64_t n_rows, const int32_t *__r
             float acc[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
-            int e = beg;
-            for (; e + 4 <= end; e += 4) {
-                float we[4];
-                float xv[4][VEC];
+            if constexpr (U == 4) {
+                int e = beg;
+                for (; e + 4 <= end; e += 4) {
+                    float we[4];
+                    float xv[4][VEC];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    we[u] = w[e + u];
-                    const int64_t s = INDEXED ? (int64_t)idx[e + u] : (int64_t)(e + u);
-                    const float *xp = X + s * ldx + c0;
-                    if constexpr (VEC == 4) {
-                        const float4 t = *reinterpret_cast<const float4 *>(xp);
-                        xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
-                    } else {
-                        xv[u][0] = xp[0];
+                    for (int u = 0; u < 4; ++u) {
+                        we[u] = w[e + u];
+                        const int64_t s = INDEXED ? (int64_t)idx[e + u] : (int64_t)(e + u);
+                        const float *xp = X + s * ldx + c0;
+                        if constexpr (VEC == 4) {
+                            const float4 t = *reinterpret_cast<const float4 *>(xp);
+                            xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                        } else {
+                            xv[u][0] = xp[0];
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we[u], xv[u][v], acc[v]);
                 }
+                for (; e < end; ++e) {
+                    const float we = w[e];
+                    const int64_t s = INDEXED ? (int64_t)idx[e] : (int64_t)e;
+                    const float *xp = X + s * ldx + c0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we, xp[v], acc[v]);
+                }
+            } else {
+                // narrow slices (feature-sliced exchange, 8 / 16 columns per rank): U entries requested together, the tail as a masked batch
+                // (clamped to a real entry, result unused) instead of one dependent round trip per entry
+                for (int e = beg; e < end; e += U) {
+                    float we[U];
+                    float xv[U][VEC];
 #pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we[u], xv[u][v], acc[v]);
-            }
-            for (; e < end; ++e) {
-                const float we = w[e];
-                const int64_t s = INDEXED ? (int64_t)idx[e] : (int64_t)e;
-                const float *xp = X + s * ldx + c0;
+                    for (int u = 0; u < U; ++u) {
+                        const int ee = e + u < end ? e + u : e;
+                        we[u] = w[ee];
+                        const int64_t s = INDEXED ? (int64_t)idx[ee] : (int64_t)ee;
+                        const float *xp = X + s * ldx + c0;
+                        if constexpr (VEC == 4) {
+                            const float4 t = *reinterpret_cast<const float4 *>(xp);
+                            xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+                        } else {
+                            xv[u][0] = xp[0];
+                        }
+                    }
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we, xp[v], acc[v]);
+                    for (int u = 0; u < U; ++u)
+                        if (e + u < end) {
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(we[u], xv[u][v], acc[v]);
+                        }
+                }
             }
             float *op = out + row * ldo + c0;
 #pragma unroll
@@ -601,8 +629,12 @@ int gnn_launch_spmm(hipStream_t st, int64_t n_rows, const int32_t *indptr, const
     const unsigned grid = (unsigned)std::min<int64_t>(cdiv(threads, 256), 256 * 32);
     const bool indexed = idx != nullptr;
     // (A one-lane-per-row form with eight entries in flight for the 8-column slices of the feature-sliced exchange was measured in round 3:
-    //  257 us against 203 us for this kernel's two lanes per row - profiles/r03_exchange_layouts.txt - and removed.)
-    if (vec4 && indexed) hipLaunchKernelGGL((k_spmm<4, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
+    //  257 us against 203 us for this kernel's two lanes per row - profiles/r03_exchange_layouts.txt - and removed.  Round 5: see below.)
+    // narrow column slices (feature-sliced exchange at 4 / 8 ranks: 16 / 8 columns of all nodes): eight entries in flight per lane and the tail as a
+    // masked batch - 183 against 204 us per rank and iteration at P = 8 (profiles/r05_slice_counters.txt).  The kernel is bound by the L2's miss path:
+    // 11.4 M 64-byte fetches per launch for 10 M random 32-byte row pieces out of a 32 MB table that no XCD's 4 MiB L2 can hold (hit rate 23 %).
+    if (vec4 && indexed && width <= 16) hipLaunchKernelGGL((k_spmm<4, true, 8>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
+    else if (vec4 && indexed) hipLaunchKernelGGL((k_spmm<4, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
     else if (vec4) hipLaunchKernelGGL((k_spmm<4, false>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
     else if (indexed) hipLaunchKernelGGL((k_spmm<1, true>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
     else hipLaunchKernelGGL((k_spmm<1, false>), grid, 256, 0, st, n_rows, indptr, idx, w, X, width, ldx, out, ldo, lpr, gate, world);
