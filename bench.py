@@ -360,7 +360,7 @@ def other_configs(engine, s, device=0):
 def profile_figures():
     """Counter-derived figures of the dominant kernel from the committed rocprofv3 PMC passes of this command
     (tools/profile.sh + tools/collect_profile.py -> profiles/<round>_pmc.json); None when no profile is committed."""
-    for tag in ('r04', 'r03', 'r02', 'r01'):
+    for tag in ('r05', 'r04', 'r03', 'r02', 'r01'):
         path = os.path.join(ROOT, 'profiles', f'{tag}_pmc.json')
         if os.path.exists(path):
             with open(path) as f:
