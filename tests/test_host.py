@@ -305,3 +305,30 @@ def test_stand_in_transport_exports_what_the_engine_binds():
     lib = ctypes.CDLL(os.path.join(root, 'tests', 'mock_rccl', 'libmock_rccl.so'))
     for name in bound:
         assert hasattr(lib, name), name
+
+
+def test_slice_exchange_switch_never_implies_the_pipelined_form(monkeypatch):
+    """Loop.set_slice_exchange: any truthy `on` - True, 1, numpy.bool_ - selects the ONE-SHOT form (code 2); the block-wise form
+    (code 1, never yet run over RCCL with more than one rank) needs the explicit keyword; falsy switches the exchange off.  No GPU: the C
+    entry point is replaced by a recorder."""
+    from GNN import _engine as e
+    calls = []
+
+    class _Lib:
+        def gnn_loop_set_slice_exchange(self, handle, code):
+            calls.append(code.value)
+            return 0
+
+    monkeypatch.setattr(e, 'lib', lambda: _Lib())
+    lp = e.Loop.__new__(e.Loop)
+    lp._h = None
+    for on in (True, 1, np.bool_(True), 2):
+        lp.set_slice_exchange(on)
+    lp.set_slice_exchange(True, form='oneshot')
+    lp.set_slice_exchange(True, form='pipelined')
+    for off in (False, 0, np.bool_(False), None):
+        lp.set_slice_exchange(off)
+    assert calls == [2, 2, 2, 2, 2, 1, 0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        lp.set_slice_exchange(True, form='fast')
+    lp._h = None          # (nothing to destroy)
