@@ -648,28 +648,29 @@ def test_lgnn_device_optimizer_matches_host_optimizer(mode):
                 assert np.max(np.abs(a - b)) <= 5e-5 * max(1.0, np.max(np.abs(a)))
 
 
-@pytest.mark.parametrize('n,with_dropout', [(6000, False), (4500, True)])
-def test_wide_layers_on_the_matrix_cores_match_oracle(n, with_dropout):
+@pytest.mark.parametrize('n,with_dropout,d,hidden', [(6000, False, 64, (128, 128)), (4500, True, 64, (128, 128)), (4200, False, 64, (100, 96)), (4131, False, 64, (72, 128)), (4300, False, 48, (100, 96))])
+def test_wide_layers_on_the_matrix_cores_match_oracle(n, with_dropout, d, hidden):
     """BASELINE configs[2] net shape (state_dim 64, 135 -> 128 -> 128 -> 64) on enough rows for the matrix-core products of the training
     step (gnn_train.hip: k_gemm_f32 forward / d h_in, k_wgrad_f32 weight gradients, k_train_input_rows): loss, k and every gradient array
     against the float64 oracle to 2e-4 of the array's largest entry (1e-3, the bar of the small-shape tests above, with Dropout in the
     net).  Measured on this step (tools/dbg/train_acc.py, profiles/r03_train_c3.txt): split-bf16 products 1.1e-4, f32-MFMA chain 3.1e-4,
     per-op FP32-ALU kernels 2.6e-4 - the bias gradients are the least accurate arrays in all three.  A repeated step gives the same bits
-    (per-chunk partials are added in a fixed order)."""
+    (per-chunk partials are added in a fixed order).  Without Dropout the backward chain of the three layers runs in ONE pass (k_bwd3_split,
+    round 5): also with hidden widths below 128 / a state narrower than 64 (zero-padded feature tiles) and a partial last 32-row tile."""
     from GNN import _engine as e
     rng = np.random.default_rng(n)
-    d, nl, al, max_it = 64, 3, 1, 3
+    nl, al, max_it = 3, 1, 3
     arcs = random_arcs(rng, n, 4 * n, al)
     nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
     g = orc.make_graph_dict(arcs, nodes, 'average')
     g['set_mask'] = rng.random(n) < 0.9
-    st = make_mlp(rng, al + 2 * (d + nl), [128, 128, d], 'selu', gain=0.7, bn_random=True)
+    st = make_mlp(rng, al + 2 * (d + nl), list(hidden) + [d], 'selu', gain=0.7, bn_random=True)
     ou = make_mlp(rng, d + nl, [2], 'softmax', batch_normalization=False)      # (BatchNormalization right after a softmax is ill-conditioned: 3e-3 in float32 whichever kernels run)
     rate = 0.1 if with_dropout else 0.0                     # Dropout behind the first hidden layer: the d h_in epilogue of the wide product
     st['dropout'], ou['dropout'] = ({1: rate} if with_dropout else {}), {}
     mask = g['set_mask'] & g['output_mask']
     m = int(mask.sum())
-    masks_s = [({1: rng.random((n, 128)) > rate} if with_dropout else {}) for _ in range(max_it)]
+    masks_s = [({1: rng.random((n, hidden[0])) > rate} if with_dropout else {}) for _ in range(max_it)]
     targets = np.eye(2)[rng.integers(0, 2, m)].astype(np.float32)
     weights = (rng.uniform(0.5, 1.5, m) / m).astype(np.float32)
     s0 = (0.1 * rng.standard_normal((n, d))).astype(np.float32)
