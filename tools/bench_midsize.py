@@ -1,7 +1,7 @@
 """Per-iteration time of the fused kernel across graph sizes (latency-bound to throughput-bound): the bench workload's generator,
 weights and arithmetic at N nodes.  Prints ms per iteration (HIP events around every launch), the algorithmic TB/s and the fraction of
-the 8 TB/s roof.  With the diagnostic build (GNN_HIP_LIBRARY=.../libgnn_hip_diag.so) GNN_FUSED_TILE16=0 / 1 forces the 32- / 16-node-tile
-kernel.     python tools/bench_midsize.py [N ...]"""
+the 8 TB/s roof.  GNN_TILE_FORM=1 / 2 forces one wave per tile (k_fused) / a wave pair per tile (k_fused_pair) on the default path; 0 (default) is the
+library's choice.     python tools/bench_midsize.py [N ...]"""
 import os
 import sys
 
@@ -21,7 +21,7 @@ def main():
     st = bench.make_net(rng, al + 2 * (nl + d), [128, 128, d], 'selu')
     ou = bench.make_net(rng, nl + d, [t], 'softmax')
     mst, mou = e.Mlp(st['weights'], st['activations'], True), e.Mlp(ou['weights'], ou['activations'], True)
-    print(f'# GNN_FUSED_TILE16={os.environ.get("GNN_FUSED_TILE16", "(auto)")} GNN_TILE_FORM={os.environ.get("GNN_TILE_FORM", "0")} library={os.path.basename(e.LIB_PATH)}')
+    print(f'# GNN_TILE_FORM={os.environ.get("GNN_TILE_FORM", "0")} library={os.path.basename(e.LIB_PATH)}')
     for n in sizes:
         s = utils.syntheticGraph(n, 10.0, nl, al, t, seed=20261003)
         n = s['n_nodes']
