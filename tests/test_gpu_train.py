@@ -664,7 +664,11 @@ def test_wide_layers_on_the_matrix_cores_match_oracle(n, with_dropout, d, hidden
     nodes = (2 * rng.random((n, nl)) - 1).astype(np.float32)
     g = orc.make_graph_dict(arcs, nodes, 'average')
     g['set_mask'] = rng.random(n) < 0.9
-    st = make_mlp(rng, al + 2 * (d + nl), list(hidden) + [d], 'selu', gain=0.7, bn_random=True)
+    # (the added shapes use a SMOOTH activation: a SELU pre-activation next to its kink flips sides between any two float32 evaluation orders, and one flip
+    #  among a few thousand rows is a 1e-4 .. 1e-3 gradient error in EVERY implementation - tools/dbg/fwd3_widths.py: per-layer forward 3e-7 / fused 1e-3 on
+    #  one shape, 1.9e-4 / 4e-7 on another - so a tight tolerance on SELU tests the seed, not the kernels)
+    act = 'selu' if (tuple(hidden) == (128, 128) and d == 64) else 'tanh'
+    st = make_mlp(rng, al + 2 * (d + nl), list(hidden) + [d], act, gain=0.7, bn_random=True)
     ou = make_mlp(rng, d + nl, [2], 'softmax', batch_normalization=False)      # (BatchNormalization right after a softmax is ill-conditioned: 3e-3 in float32 whichever kernels run)
     rate = 0.1 if with_dropout else 0.0                     # Dropout behind the first hidden layer: the d h_in epilogue of the wide product
     st['dropout'], ou['dropout'] = ({1: rate} if with_dropout else {}), {}
@@ -689,9 +693,7 @@ def test_wide_layers_on_the_matrix_cores_match_oracle(n, with_dropout, d, hidden
     assert abs(res['loss'] - ref['loss']) <= 2e-5 * max(1.0, abs(ref['loss']))
     pairs = list(zip(res['grads_state'], ref['grads_state'])) + list(zip(res['grads_output'], ref['grads_output']))
     scale = max(float(np.max(np.abs(want))) for _, want in pairs)           # the largest gradient entry of the step
-    # (2e-4 is what the BASELINE shape measures; a SELU pre-activation next to its kink flips sides between any two float32 evaluation orders - the fused
-    #  and the per-layer forward differ by 3e-4 .. 8e-4 on these shapes, tools/dbg/fwd3_widths.py - so the other shapes get the general bar of the step)
-    tol = 1e-3 if (with_dropout or tuple(hidden) != (128, 128) or d != 64) else 2e-4
+    tol = 1e-3 if with_dropout else 2e-4
     for got, want in pairs:
         assert got.shape == want.shape
         # relative to the array's largest entry, but not below a tenth of the step's gradient scale (the small bias / BatchNormalization vectors)

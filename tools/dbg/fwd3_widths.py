@@ -29,4 +29,9 @@ loop.set_state0(s0)
 r = loop.train_step(mst, mou, None, targets, weights, 0, None, dropout_state=[0, 0, 0, 0], dropout_output=[0, 0], bn_state=np.concatenate(st['weights'][-4:-2]), bn_output=None)
 out = os.environ.get('OUT')
 np.savez(out, loss=r['loss'], **{f'gs{i}': a for i, a in enumerate(r['grads_state'])})
+if os.environ.get('ORACLE'):
+    from oracle import gnn_train_oracle as tro
+    g['set_mask'] = mask
+    ref = tro.train_step(g, st, ou, d, max_it, 0.0, s0, [{} for _ in range(max_it)], {}, targets, weights, loss='categorical_crossentropy', mean=False, graph_based=False)
+    np.savez(os.environ['ORACLE'], loss=ref['loss'], **{f'gs{i}': a for i, a in enumerate(ref['grads_state'])})
 print(os.environ.get('GNN_TRAIN_FWD3'), os.environ.get('GNN_TRAIN_BWD3'), 'loss', r['loss'])
