@@ -1225,6 +1225,11 @@ struct Bwd3Args {
     const float *DZ2, *A1, *A0;
     const uint32_t *img;
     float *DZ1, *DZ0, *DINP;
+    // optional (DSG != nullptr): the two column blocks of d inp the state gradient reads - own state [0, Ds) and aggregated state [c_aggs, c_aggs + Ds) -
+    // once more as 16-byte aligned rows [n, 2 Ds] (the concat's rows are 135 floats long and its aggregate block starts at column 67: k_state_grad_rows
+    // gathers ten rows of it per node with 4-byte loads; from the aligned copy with 16-byte loads)
+    float *DSG;
+    int Ds, c_aggs;
 };
 
 __global__ void __launch_bounds__(64 * TG_WAVES, 2) k_bwd3_split(const Bwd3Args p)
@@ -1366,6 +1371,15 @@ __global__ void __launch_bounds__(64 * TG_WAVES, 2) k_bwd3_split(const Bwd3Args 
                 else
                     for (int t = 0; t < 4; ++t) if (e + t < total) gptr_w(dst)[e + t] = v[t];
             }
+            if (p.DSG) {                                                 // [own | aggregate] column blocks as aligned rows
+                const int Ds = p.Ds, ppr = Ds >> 1;                      // 16-byte pieces per row of the copy (2 Ds floats)
+                float *sg = p.DSG + i0 * 2 * Ds;
+                for (int idx = lane_p; idx < nvalid * ppr; idx += 64) {
+                    const int r = idx / ppr, q = idx - r * ppr, c = 4 * q < Ds ? 4 * q : p.c_aggs + (4 * q - Ds);
+                    const float *x = X + r * KP + c;
+                    *reinterpret_cast<GNN_GLOBAL v4f *>(gptr_w(sg) + r * 2 * Ds + 4 * q) = v4f{x[0], x[1], x[2], x[3]};
+                }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
     }
@@ -1379,7 +1393,7 @@ inline bool bwd3_covers(const gnn_mlp *m)
 // WT[l]: the transposed kernels [n_out, n_in] of the three layers (Net::WT)
 template <class BufT>
 int launch_bwd3(hipStream_t st, BufT &buf, const gnn_mlp *m, float *const *WT, int64_t n, const float *dz2, const float *a1, const float *a0, float *dz1,
-                float *dz0, float *dinp)
+                float *dz0, float *dinp, float *dsg = nullptr, int Ds = 0, int c_aggs = 0)
 {
     static bool raised = false;
     if (!raised) {
@@ -1403,6 +1417,7 @@ int launch_bwd3(hipStream_t st, BufT &buf, const gnn_mlp *m, float *const *WT, i
     p.img = img; p.img_bytes = (int)((dA + dB + dC + dD) * sizeof(uint32_t));
     p.offB = (int)(dA * sizeof(uint32_t)); p.offC = (int)((dA + dB) * sizeof(uint32_t)); p.offD = (int)((dA + dB + dC) * sizeof(uint32_t));
     p.DZ2 = dz2; p.A1 = a1; p.A0 = a0; p.DZ1 = dz1; p.DZ0 = dz0; p.DINP = dinp;
+    p.DSG = dsg; p.Ds = Ds; p.c_aggs = c_aggs;
     const size_t lds = sizeof(float) * ((size_t)TG_WAVES * 32 * p.KP + 32 + 128) + 16;
     if (lds > 160 * 1024) return gnn_fail(GNN_ERR_UNSUPPORTED, "fused backward: LDS");
     const int64_t n_tiles = (n + 31) / 32;
@@ -1820,6 +1835,37 @@ __global__ void __launch_bounds__(256) k_state_grad_rows(int64_t n, int Ds, int 
     *reinterpret_cast<float4 *>(d_state + r * Ds + cc) = float4{own[0] + acc[0], own[1] + acc[1], own[2] + acc[2], own[3] + acc[3]};
 }
 
+// The same from the aligned copy k_bwd3_split leaves (dsg [n, 2 Ds] = [d inp[:, :Ds] | d inp[:, c_aggs : c_aggs + Ds]]): 16-byte loads, eight arcs in
+// flight per lane, same fmaf chain per element.
+__global__ void __launch_bounds__(256) k_state_grad_rows_al(int64_t n, int Ds, const float *__restrict__ dsg, const int32_t *__restrict__ sip,
+                                                            const int32_t *__restrict__ sdst, const float *__restrict__ sw, float *__restrict__ d_state)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = t >> 4;
+    const int cc = 4 * (int)(t & 15);
+    if (r >= n || cc >= Ds) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int32_t e1 = sip[r + 1];
+    for (int32_t e = sip[r]; e < e1; e += 8) {
+        float w[8];
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int32_t ee = e + u < e1 ? e + u : e;                   // clamp: a real entry, result unused
+            w[u] = sw[ee];
+            x[u] = *reinterpret_cast<const float4 *>(dsg + (int64_t)sdst[ee] * 2 * Ds + Ds + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e + u < e1) {
+                acc[0] = __builtin_fmaf(w[u], x[u].x, acc[0]); acc[1] = __builtin_fmaf(w[u], x[u].y, acc[1]);
+                acc[2] = __builtin_fmaf(w[u], x[u].z, acc[2]); acc[3] = __builtin_fmaf(w[u], x[u].w, acc[3]);
+            }
+    }
+    const float4 own = *reinterpret_cast<const float4 *>(dsg + r * 2 * Ds + cc);
+    *reinterpret_cast<float4 *>(d_state + r * Ds + cc) = float4{own.x + acc[0], own.y + acc[1], own.z + acc[2], own.w + acc[3]};
+}
+
 __global__ void k_gather_feats(int64_t m, const int32_t *rows, const float *state, int Ds, const float *nodes, int NL, int NLc, float *feats)
 {
     const int wf = Ds + NLc;
@@ -2221,6 +2267,7 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
     }
     // d is d loss / d z of layer l at the top of every pass
     // a 3-layer net without Dropout on many rows: the whole chain d z2 -> d z1 -> d z0 -> d inp in one pass (k_bwd3_split), then the three weight gradients
+    float *dsg = nullptr;
     bool chain3 = n > 0 && L == 3 && tg_many_rows(n) && bwd3_covers(m) && net.rate[0] == 0.0f && net.rate[1] == 0.0f && net.rate[2] == 0.0f;
     for (int l = 0; l < 3 && chain3; ++l) chain3 = tg_wide(m->dims[l + 1], m->dims[l]) && tg_wgrad_covers(m->dims[l], m->dims[l + 1]);
 #ifdef GNN_DIAG
@@ -2230,7 +2277,9 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
     if (chain3) {
         float *dz1 = nullptr, *dz0 = nullptr, *dinp = nullptr;
         if ((rc = buf.get(&dz1, (size_t)n * m->dims[2])) || (rc = buf.get(&dz0, (size_t)n * m->dims[1])) || (rc = buf.get(&dinp, (size_t)n * m->dims[0]))) return rc;
-        if ((rc = launch_bwd3(st, buf, m, net.WT.data(), n, d, c.a[1], c.a[0], dz1, dz0, dinp))) return rc;
+        // the state gradient of this body reads two column blocks of d inp: the chain leaves them once more as aligned rows
+        if (job && job->N == n && (job->Ds & 3) == 0 && job->Ds <= 64 && job->in_s == m->dims[0] && (rc = buf.get(&dsg, (size_t)n * 2 * job->Ds))) return rc;
+        if ((rc = launch_bwd3(st, buf, m, net.WT.data(), n, d, c.a[1], c.a[0], dz1, dz0, dinp, dsg, job ? job->Ds : 0, job ? job->c_aggs : 0))) return rc;
         const float *dzs[3] = {dz0, dz1, d};
         for (int l = 2; l >= 0; --l)
             if ((rc = launch_wgrad_f32(st, n, rpb, parts, ps, m->dims[l], m->dims[l + 1], c.hin[l], dzs[l], net.part + net.g_off[2 * l]))) return rc;
@@ -2268,7 +2317,10 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         d = dprev;
     }
     const unsigned sum_blocks = cdiv((int64_t)net.g_total, 64);
-    if (job && tg_many_rows(job->N) && (job->Ds & 3) == 0 && job->Ds <= 64) {
+    if (job && dsg) {
+        hipLaunchKernelGGL(k_state_grad_rows_al, cdiv(job->N * 16, 256), 256, 0, st, job->N, job->Ds, dsg, job->sip, job->sdst, job->sw, job->d_state);
+        hipLaunchKernelGGL(k_sum_parts, sum_blocks, 256, 0, st, parts, (int64_t)net.g_total, net.part, net.grads);
+    } else if (job && tg_many_rows(job->N) && (job->Ds & 3) == 0 && job->Ds <= 64) {
         hipLaunchKernelGGL(k_state_grad_rows, cdiv(job->N * 16, 256), 256, 0, st, job->N, job->Ds, job->in_s, job->c_aggs, d, job->sip, job->sdst, job->sw, job->d_state);
         hipLaunchKernelGGL(k_sum_parts, sum_blocks, 256, 0, st, parts, (int64_t)net.g_total, net.part, net.grads);
     } else if (job && job->N > 0) {
