@@ -29,14 +29,19 @@ sq, inst = pmc(d + 'pmc_sq/pmc_counter_collection.csv'), pmc(d + 'pmc_inst/pmc_c
 ks, ki = [n for n in sq if 'k_fused' in n and 'true' in n][0], [n for n in inst if 'k_fused' in n and 'true' in n][0]
 cycles = avg(f[k]['GRBM_GUI_ACTIVE']) / 8.0            # GRBM_GUI_ACTIVE is summed over the 8 XCDs
 rows_stats = [r for r in csv.DictReader(open(d + 'stats/stats_kernel_stats.csv')) if r['Name'] == k]
-prof_ms = float(rows_stats[0]['AverageNs']) / 1e6 if rows_stats else None
+prof_ms_all = float(rows_stats[0]['AverageNs']) / 1e6 if rows_stats else None
+# what bench.py's staleness guard compares with its live HIP-event mean: the launches of the two TIMED Loops of the traced run (launches 30 .. 89: Loop 0
+# is the warm-up), not the mean over all launches (which also holds the warm-up, the cold-aggregates and the PCIe-inclusive Loops: 4 - 5 % higher)
+_tr = [r for r in csv.DictReader(open(d + 'stats/stats_kernel_trace.csv')) if r['Kernel_Name'] == k]
+_dur = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in _tr]
+prof_ms = sum(_dur[30:90]) / 60 if len(_dur) >= 90 else prof_ms_all
 n_tiles = 31250
 fig = {'kernel': k, 'hbm_bytes_per_launch': out['hbm_bytes_per_launch'],
        'mfma_busy_pct': 100.0 * avg(sq[ks]['SQ_VALU_MFMA_BUSY_CYCLES']) / (1024 * cycles),
        'valu_busy_pct': 100.0 * 4.0 * avg(sq[ks]['SQ_ACTIVE_INST_VALU']) / (1024 * cycles),
        'lds_bank_conflict_share': avg(inst[ki]['SQ_LDS_BANK_CONFLICT']) / avg(inst[ki]['SQ_ACTIVE_INST_LDS']),
        'valu_insts_per_tile': avg(inst[ki]['SQ_INSTS_VALU']) / n_tiles, 'mfma_insts_per_tile': avg(inst[ki]['SQ_INSTS_MFMA']) / n_tiles,
-       'effective_clock_ghz': cycles / (prof_ms * 1e6) if prof_ms else None, 'profiled_avg_launch_ms': prof_ms,
+       'effective_clock_ghz': cycles / (prof_ms_all * 1e6) if prof_ms_all else None, 'profiled_avg_launch_ms': prof_ms, 'profiled_avg_launch_ms_all_launches': prof_ms_all,
        'definitions': 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles); valu_busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / '
                       'the same; kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; lds_bank_conflict_share = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS; '
                       'per launch averages over all launches of the kernel in `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`'}
