@@ -1510,6 +1510,89 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_f32(const WgradArgs p)
         }
 }
 
+// The same partials in the split arithmetic of the dense layers (round 5): every fp32 operand cut into three exact bf16 pieces, six piece
+// products per term on v_mfma_f32_32x32x16_bf16, fp32 accumulation (error per product <= 3 * 2^-24: fp32-class, run-to-run identical).  Rows are
+// the K dimension, 16 per step: lane (m, k half) takes H[r + 8 k half + i][32 a + m], i < 8 - eight coalesced 128-byte row pieces per operand
+// tile, no transposition - and cuts them in registers.  What the round-3 experiment of this (below, 0.92 ms against 0.42) lacked: its 5 x 2
+// accumulator tiles (160 registers) left no room to have the next step's rows in flight.  Here a block is EIGHT waves: wave w owns d z tile
+// w % NT for ALL tiles of [H | 1] (MT x 16 accumulator registers) on rows part w / NT of the chunk, the next step's 8 (MT + 1) row pieces are
+// requested before the current step's products, and the 8 / NT partial tiles of an output are added in part order through LDS.
+template <int MT, int NT>
+__global__ void __launch_bounds__(512, 2) k_wgrad_bf(const WgradArgs p)
+{
+    using namespace gnn_fused_dev;
+    __shared__ float red[8][1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 31, kh = lane >> 5;
+    constexpr int NP = 8 / NT;                                                     // row parts of a chunk
+    const int b = wave % NT, part = wave / NT;
+    const int64_t c0 = (int64_t)blockIdx.x * p.rows_per_block, c1 = c0 + p.rows_per_block < p.n ? c0 + p.rows_per_block : p.n;
+    const int64_t span = ((c1 - c0 + NP - 1) / NP + 15) & ~(int64_t)15;             // whole K = 16 steps
+    const int64_t r0 = c0 + part * span, r1 = r0 + span < c1 ? r0 + span : c1;
+    const int zf = 32 * b + m;
+    const bool zok = zf < p.n_out;
+    f32x16 acc[MT];
+    zero_acc<MT>(acc);
+    // ONE register set: a tile's eight row pieces are requested again for the NEXT step as soon as this step has cut them into pieces, i.e. a
+    // whole step (6 MT MFMAs) ahead of their use (two sets, loaded a step ahead as a block: 28 registers spilled at MT = 5)
+    float hv[MT][8], zv[8];
+    auto load_z = [&](int64_t r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r + 8 * kh + i;
+            zv[i] = (rr < r1 && zok) ? gload1(p.DZ + rr * p.n_out + zf) : 0.0f;
+        }
+    };
+    auto load_h = [&](int a, int64_t r) {
+        const int hf = 32 * a + m;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r + 8 * kh + i;
+            hv[a][i] = rr < r1 ? (hf < p.n_in ? gload1(p.H + rr * p.n_in + hf) : (hf == p.n_in ? 1.0f : 0.0f)) : 0.0f;
+        }
+    };
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    if (r0 < r1) {
+        load_z(r0);
+#pragma unroll
+        for (int a = 0; a < MT; ++a) load_h(a, r0);
+    }
+    for (int64_t r = r0; r < r1; r += 16) {
+        v4i pb[3];
+        split8(zv, pb[0], pb[1], pb[2]);
+        load_z(r + 16);                                                             // (rows past r1 load zeros: no guard around the requests)
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+            v4i pa[3];
+            split8(hv[a], pa[0], pa[1], pa[2]);
+            load_h(a, r + 16);
+#pragma unroll
+            for (int term = 0; term < 6; ++term) acc[a] = mfma_bf16(pa[PA[term]], pb[PB[term]], acc[a]);
+        }
+    }
+    // D[row hf = 32 a + (r & 3) + 8 (r >> 2) + 4 kh][col zf]
+    float *out = p.part + (size_t)blockIdx.x * p.pstride;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+        if (part > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave][r * 64 + lane] = acc[a][r];
+        }
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[a][r];
+#pragma unroll
+                for (int q = 1; q < NP; ++q) v = v + red[b + NT * q][r * 64 + lane];
+                const int hf = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (hf <= p.n_in && zok) out[(size_t)hf * p.n_out + zf] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 #ifdef GNN_DIAG
 // EXPERIMENT (diagnostic build, GNN_TRAIN_WGRAD_SPLIT=1; round 3): the same partials in split arithmetic (three exact bf16 pieces per
 // operand, six piece products on v_mfma_f32_32x32x16_bf16): rows are the K dimension, 16 per step - lane (m, k half) holds
@@ -1598,6 +1681,18 @@ int launch_wgrad_f32(hipStream_t st, int64_t n, int64_t rpb, int parts, int64_t 
     WgradArgs p{n, rpb, pstride, n_in, n_out, H, DZ, part};
     const int mt = (n_in + 1 + 31) / 32, nt = (n_out + 31) / 32;
     const int nt2 = nt >= 2 ? 2 : 1;
+    {   // split-bf16 form (k_wgrad_bf) when the d z tiles divide the eight waves of a block; the f32-MFMA form (k_wgrad_f32) otherwise
+        bool bf = nt == 1 || nt == 2 || nt == 4;
+#ifdef GNN_DIAG
+        static const bool bf_off = getenv("GNN_TRAIN_WGRAD_BF") && atoi(getenv("GNN_TRAIN_WGRAD_BF")) == 0;
+        if (bf_off) bf = false;
+#endif
+        if (bf) {
+#define GNN_WGB_CASE(M_, N_) if (mt == M_ && nt == N_) { hipLaunchKernelGGL((k_wgrad_bf<M_, N_>), dim3((unsigned)parts), 512, 0, st, p); HIPCHK(hipGetLastError()); return GNN_OK; }
+            GNN_WGB_CASE(3, 1) GNN_WGB_CASE(3, 2) GNN_WGB_CASE(3, 4) GNN_WGB_CASE(4, 1) GNN_WGB_CASE(4, 2) GNN_WGB_CASE(4, 4) GNN_WGB_CASE(5, 1) GNN_WGB_CASE(5, 2) GNN_WGB_CASE(5, 4)
+#undef GNN_WGB_CASE
+        }
+    }
     const dim3 grid((unsigned)parts, (unsigned)((nt + nt2 - 1) / nt2));
 #ifdef GNN_DIAG
     static const bool split = getenv("GNN_TRAIN_WGRAD_SPLIT") != nullptr;
