@@ -1593,115 +1593,6 @@ __global__ void __launch_bounds__(512, 2) k_wgrad_bf(const WgradArgs p)
     }
 }
 
-// k_wgrad_bf for FOUR d z tiles (n_out in (96, 128]) with the rows staged ONCE per block (round 5).  In k_wgrad_bf the four waves that share a rows part
-// each request the same 8 MT row pieces of H per step - the CU's vector-memory pipe, not the matrix pipe, bounds it (0.37 ms per 1 M x 129 x 128
-// gradient).  Here the block's 512 threads copy a 32-row slab of H and of d z into LDS as it lies in memory - aligned 16-byte pieces of the slab's
-// flat extent (32 n_in floats start on a 16-byte boundary whatever n_in is), row stride n_in / n_out floats - and wave w multiplies K-step w / 4 of
-// the slab (16 rows) for d z tile w % 4 with all MT tiles of [H | 1]: lane (feature, k half) reads its feature in 8 consecutive rows (32 consecutive
-// lanes = 32 consecutive floats per read: conflict-free).  Two slab buffers: the next slab's loads are in flight during this slab's products, one
-// __syncthreads() per slab.
-template <int MT>
-__global__ void __launch_bounds__(512, 2) k_wgrad_lds(const WgradArgs p)
-{
-    using namespace gnn_fused_dev;
-    extern __shared__ __attribute__((aligned(16))) float wl[];
-    constexpr int HMAX = 32 * 32 * MT, ZMAX = 32 * 128;                             // floats of a slab of H (n_in <= 32 MT) / of d z
-    float *HS = wl, *ZS = wl + 2 * HMAX, *red = ZS + 2 * ZMAX;                       // HS[2][32 n_in], ZS[2][32 n_out], red[4][1024]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31, kh = lane >> 5, b = wave & 3, ks = wave >> 2;
-    const int64_t c0 = (int64_t)blockIdx.x * p.rows_per_block, c1 = c0 + p.rows_per_block < p.n ? c0 + p.rows_per_block : p.n;
-    const int n_in = p.n_in, n_out = p.n_out;
-    f32x16 acc[MT];
-    zero_acc<MT>(acc);
-    constexpr int QH = (HMAX / 4 + 511) / 512, QZ = (ZMAX / 4 + 511) / 512;        // 16-byte pieces per thread
-    v4f hq[QH], zq[QZ];
-    auto request = [&](int64_t row0) {          // the slab's flat extents; elements past the chunk's end read as zero
-        const int valid = (int)((c1 - row0) < 32 ? (c1 - row0) : 32);
-        const int nh = valid * n_in, nz = valid * n_out;
-        const float *hs = p.H + row0 * n_in, *zs = p.DZ + row0 * n_out;
-#pragma unroll
-        for (int q = 0; q < QH; ++q) {
-            const int e = 4 * (tid + 512 * q);
-            hq[q] = v4f{0.f, 0.f, 0.f, 0.f};
-            if (e + 4 <= nh) hq[q] = gload4(hs + e);
-            else if (e < nh) { float t4[4] = {0.f, 0.f, 0.f, 0.f}; for (int u = 0; u < 4; ++u) if (e + u < nh) t4[u] = gload1(hs + e + u); hq[q] = v4f{t4[0], t4[1], t4[2], t4[3]}; }
-        }
-#pragma unroll
-        for (int q = 0; q < QZ; ++q) {
-            const int e = 4 * (tid + 512 * q);
-            zq[q] = v4f{0.f, 0.f, 0.f, 0.f};
-            if (e + 4 <= nz) zq[q] = gload4(zs + e);
-            else if (e < nz) { float t4[4] = {0.f, 0.f, 0.f, 0.f}; for (int u = 0; u < 4; ++u) if (e + u < nz) t4[u] = gload1(zs + e + u); zq[q] = v4f{t4[0], t4[1], t4[2], t4[3]}; }
-        }
-    };
-    auto stage = [&](int buf) {
-        float *hs = HS + buf * HMAX, *zs = ZS + buf * ZMAX;
-#pragma unroll
-        for (int q = 0; q < QH; ++q) {
-            const int e = 4 * (tid + 512 * q);
-            if (e < 32 * n_in) *reinterpret_cast<v4f *>(hs + e) = hq[q];           // (32 n_in is a multiple of 4)
-        }
-#pragma unroll
-        for (int q = 0; q < QZ; ++q) {
-            const int e = 4 * (tid + 512 * q);
-            if (e < 32 * n_out) *reinterpret_cast<v4f *>(zs + e) = zq[q];
-        }
-    };
-    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-    if (c0 < c1) { request(c0); stage(0); }
-    __syncthreads();
-    int buf = 0;
-    const int zf = 32 * b + m;
-    const bool zok = zf < n_out;
-    for (int64_t row0 = c0; row0 < c1; row0 += 32, buf ^= 1) {
-        const bool more = row0 + 32 < c1;
-        if (more) request(row0 + 32);           // in flight during this slab's products
-        {
-            const int valid = (int)((c1 - row0) < 32 ? (c1 - row0) : 32);
-            const int rb = 16 * ks + 8 * kh;    // this lane's 8 rows of the slab
-            const float *hs = HS + buf * HMAX + rb * n_in, *zs = ZS + buf * ZMAX + rb * n_out + (zok ? zf : 0);
-            float zv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) zv[i] = zok ? zs[i * n_out] : 0.0f;
-            v4i pb[3];
-            split8(zv, pb[0], pb[1], pb[2]);
-#pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int hf = 32 * a + m;
-                float hv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) hv[i] = hf < n_in ? hs[i * n_in + hf] : ((hf == n_in && rb + i < valid) ? 1.0f : 0.0f);       // the ones column of [H | 1]
-                v4i pa[3];
-                split8(hv, pa[0], pa[1], pa[2]);
-#pragma unroll
-                for (int term = 0; term < 6; ++term) acc[a] = mfma_bf16(pa[PA[term]], pb[PB[term]], acc[a]);
-            }
-        }
-        if (more) stage(buf ^ 1);
-        __syncthreads();
-    }
-    // D[row hf = 32 a + (r & 3) + 8 (r >> 2) + 4 kh][col zf]: the two K-step halves of an output added in order through LDS
-    float *out = p.part + (size_t)blockIdx.x * p.pstride;
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-        if (ks == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[b * 1024 + r * 64 + lane] = acc[a][r];
-        }
-        __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[a][r] + red[b * 1024 + r * 64 + lane];
-                const int hf = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (hf <= n_in && zok) out[(size_t)hf * n_out + zf] = v;
-            }
-        }
-        __syncthreads();
-    }
-}
-inline size_t wgrad_lds_bytes(int mt) { return sizeof(float) * ((size_t)2 * (32 * 32 * mt + 32 * 128) + 4 * 1024); }
-
 #ifdef GNN_DIAG
 // EXPERIMENT (diagnostic build, GNN_TRAIN_WGRAD_SPLIT=1; round 3): the same partials in split arithmetic (three exact bf16 pieces per
 // operand, six piece products on v_mfma_f32_32x32x16_bf16): rows are the K dimension, 16 per step - lane (m, k half) holds
@@ -1796,26 +1687,6 @@ int launch_wgrad_f32(hipStream_t st, int64_t n, int64_t rpb, int parts, int64_t 
         static const bool bf_off = getenv("GNN_TRAIN_WGRAD_BF") && atoi(getenv("GNN_TRAIN_WGRAD_BF")) == 0;
         if (bf_off) bf = false;
 #endif
-        bool staged = bf && nt == 4;             // four d z tiles: rows staged once per block through LDS (k_wgrad_lds)
-#ifdef GNN_DIAG
-        static const bool lds_off = getenv("GNN_TRAIN_WGRAD_LDS") && atoi(getenv("GNN_TRAIN_WGRAD_LDS")) == 0;
-        if (lds_off) staged = false;
-#endif
-        if (staged) {
-            static bool raised = false;
-            if (!raised) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_lds<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_lds<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_lds<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                raised = true;
-            }
-            const size_t lds = wgrad_lds_bytes(mt);
-            if (mt == 3) hipLaunchKernelGGL((k_wgrad_lds<3>), dim3((unsigned)parts), 512, lds, st, p);
-            else if (mt == 4) hipLaunchKernelGGL((k_wgrad_lds<4>), dim3((unsigned)parts), 512, lds, st, p);
-            else hipLaunchKernelGGL((k_wgrad_lds<5>), dim3((unsigned)parts), 512, lds, st, p);
-            HIPCHK(hipGetLastError());
-            return GNN_OK;
-        }
         if (bf) {
 #define GNN_WGB_CASE(M_, N_) if (mt == M_ && nt == N_) { hipLaunchKernelGGL((k_wgrad_bf<M_, N_>), dim3((unsigned)parts), 512, 0, st, p); HIPCHK(hipGetLastError()); return GNN_OK; }
             GNN_WGB_CASE(3, 1) GNN_WGB_CASE(3, 2) GNN_WGB_CASE(3, 4) GNN_WGB_CASE(4, 1) GNN_WGB_CASE(4, 2) GNN_WGB_CASE(4, 4) GNN_WGB_CASE(5, 1) GNN_WGB_CASE(5, 2) GNN_WGB_CASE(5, 4)
