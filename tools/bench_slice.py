@@ -31,6 +31,7 @@ for r in range(world):
         gr = e.Graph(n, ip, src, w, aw, al_, s['nodes'], np.ones(nr, np.uint8), row_begin=rb)
     lp = e.Loop(gr, mst, mou, d, iters, 0.0, comms[r])
     lp.set_impl(2)
+    lp.set_tile_form(int(os.environ.get('GNN_TILE_FORM', 0)))       # 1 / 2: force one wave / a wave pair per tile on the owned rows
     lp.set_state0(state0[rb:rb + nr])
     if layout == 'slice':
         gr.set_full_adjacency(n, s['indptr'], s['adj_src'], s['adj_w'])
