@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box, round 5: training-step kernel breakdown, 4-rank stand-in rehearsals of bench.py at full size, counters of the sliced aggregation
+# GPU box, round 5 (first batch; the training table of the FINAL code is profiles/r05_train_c3.txt): training-step kernel breakdown, 4-rank stand-in rehearsals of bench.py at full size, counters of the sliced aggregation
 export TMPDIR=/tmp
 O=$PWD/gpurun_out
 mkdir -p $O
