@@ -319,116 +319,6 @@ __global__ void __launch_bounds__(256) k_bn_apply(int64_t n, int F, int cw_shift
     }
 }
 
-// Small batches (round 5): statistics AND normalisation in one launch, every block computing the statistics of ALL rows itself.  A thread holds its
-// column's values of up to 64 rows in registers (all requested before the first is used: one memory round trip, both passes of the variance from
-// registers), 256 / CW row lanes per column are added in lane order through LDS - the same numbers in every block, so the result does not depend on
-// the grid - and the block then normalises its own share of the elements.  n <= 64 x (256 / CW) rows, F <= CW <= 32 columns (a MUTAG batch: 970 x 14).
-// Replaces k_bn_stats + k_bn_apply (4.8 + 6.6 us per call at that size: each a launch and a round trip of its own).
-constexpr int BN_SMALL_R = 64;
-inline bool bn_small_ok(int64_t n, int F)
-{
-#ifdef GNN_DIAG
-    static const bool off = getenv("GNN_TRAIN_BN_SMALL") && atoi(getenv("GNN_TRAIN_BN_SMALL")) == 0;
-    if (off) return false;
-#endif
-    return F <= 32 && n > 0 && n <= (int64_t)BN_SMALL_R * (256 >> column_shift(F));
-}
-
-__global__ void __launch_bounds__(256) k_bn_small(int64_t n, int F, int cw_shift, const float *__restrict__ h, float eps, const float *gamma, const float *beta,
-                                                  float *xhat, float *y, float *stats)
-{
-    __shared__ float s0[256];
-    __shared__ float sm[32], sinv[32];
-    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
-    const int c = threadIdx.x & (CW - 1), ry = threadIdx.x >> cw_shift;
-    const bool col = c < F;
-    float v[BN_SMALL_R];
-#pragma unroll
-    for (int q = 0; q < BN_SMALL_R; ++q) {
-        const int64_t r = ry + (int64_t)q * RL;
-        v[q] = (col && r < n) ? h[r * F + c] : 0.0f;
-    }
-    float a0 = 0.0f;
-#pragma unroll
-    for (int q = 0; q < BN_SMALL_R; ++q) a0 += v[q];
-    s0[threadIdx.x] = a0;
-    __syncthreads();
-    if (ry == 0) {
-        for (int t = 1; t < RL; ++t) a0 += s0[t * CW + c];
-        sm[c] = a0 / (float)n;
-    }
-    __syncthreads();
-    const float mean = sm[c];
-    a0 = 0.0f;
-#pragma unroll
-    for (int q = 0; q < BN_SMALL_R; ++q) {
-        const float dv = v[q] - mean;
-        a0 += (ry + (int64_t)q * RL < n) ? dv * dv : 0.0f;
-    }
-    __syncthreads();
-    s0[threadIdx.x] = a0;
-    __syncthreads();
-    if (ry == 0 && col) {
-        for (int t = 1; t < RL; ++t) a0 += s0[t * CW + c];
-        const float var = a0 / (float)n;
-        sinv[c] = 1.0f / sqrtf(var + eps);
-        if (blockIdx.x == 0) { stats[c] = mean; stats[F + c] = var; }
-    }
-    __syncthreads();
-    const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const int j = (int)((unsigned)i % (unsigned)F);
-        const float xh = (h[i] - sm[j]) * sinv[j];
-        xhat[i] = xh;
-        y[i] = gamma[j] * xh + beta[j];
-    }
-}
-
-// The backward counterpart: sum d y xhat and sum d y over ALL rows in every block (two values per row in registers), then d x of the block's own elements into
-// a NEW array (every block reads all of d y: in place would race), fused with the derivative of the layer's activation as k_bn_bwd_apply.  Block 0 leaves the
-// two sums as chunk 0 of the gradient partials of gamma / beta and zeroes the other chunks (k_sum_parts adds the chunks up).
-__global__ void __launch_bounds__(256) k_bn_bwd_small(int64_t n, int F, int cw_shift, const float *__restrict__ d, const float *__restrict__ xhat, const float *gamma,
-                                                      const float *stats, float eps, float *p_dyx, float *p_dy, int64_t pstride, int parts,
-                                                      const float *__restrict__ a, int act, float *__restrict__ dx)
-{
-    __shared__ float s0[256], s1[256];
-    __shared__ float s_dyx[32], s_dy[32];
-    const int CW = 1 << cw_shift, RL = 256 >> cw_shift;
-    const int c = threadIdx.x & (CW - 1), ry = threadIdx.x >> cw_shift;
-    const bool col = c < F;
-    float dv[BN_SMALL_R], xv[BN_SMALL_R];
-#pragma unroll
-    for (int q = 0; q < BN_SMALL_R; ++q) {
-        const int64_t r = ry + (int64_t)q * RL;
-        const bool in = col && r < n;
-        dv[q] = in ? d[r * F + c] : 0.0f;
-        xv[q] = in ? xhat[r * F + c] : 0.0f;
-    }
-    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-    for (int q = 0; q < BN_SMALL_R; ++q) { a0 += dv[q] * xv[q]; a1 += dv[q]; }
-    s0[threadIdx.x] = a0; s1[threadIdx.x] = a1;
-    __syncthreads();
-    if (ry == 0 && col) {
-        for (int t = 1; t < RL; ++t) { a0 += s0[t * CW + c]; a1 += s1[t * CW + c]; }
-        s_dyx[c] = a0; s_dy[c] = a1;
-        if (blockIdx.x == 0) {
-            p_dyx[c] = a0; p_dy[c] = a1;
-            for (int z = 1; z < parts; ++z) { p_dyx[(size_t)z * pstride + c] = 0.0f; p_dy[(size_t)z * pstride + c] = 0.0f; }
-        }
-    }
-    __syncthreads();
-    const int64_t total = n * F, step = (int64_t)gridDim.x * blockDim.x;
-    const float m = (float)n;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
-        const int j = (int)((unsigned)i % (unsigned)F);
-        const float inv = 1.0f / sqrtf(stats[F + j] + eps), g = gamma[j];
-        float v = inv / m * (m * d[i] * g - g * s_dy[j] - xhat[i] * g * s_dyx[j]);
-        if (act >= 0) v = v * act_grad(a[i], act);
-        dx[i] = v;
-    }
-}
-
 // (Round 3 tried BatchNormalization of a small batch as ONE single-block launch per direction - statistics + apply, column sums + apply,
 //  matrices staged in LDS, tree-reduced column sums - to save two launches per call: SLOWER than the two multi-block kernels at MUTAG size,
 //  0.85 against 0.76 ms per 10-body step and 3.0 against 2.6 ms per 50-body step: one workgroup's latency chain against a few microseconds
@@ -2384,13 +2274,9 @@ int net_forward(hipStream_t st, Buf &buf, Net &net, int64_t n, float *x, uint8_t
             float *part = nullptr;
             if ((rc = buf.get(&part, (size_t)parts * 2 * F))) return rc;
             const int cs = column_shift(F);
-            if (bn_small_ok(n, F))      // small batch: statistics and normalisation in one launch
-                hipLaunchKernelGGL(k_bn_small, elementwise_grid(n * F), 256, 0, st, n, F, cs, h, m->eps, net.gamma, net.beta, c.xhat, y, c.stats);
-            else {
-                hipLaunchKernelGGL(k_bn_stats, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, h, part, rpb);
-                hipLaunchKernelGGL(k_bn_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, h, part, parts, rpb, m->eps, net.gamma,
-                                   net.beta, c.xhat, y, c.stats);
-            }
+            hipLaunchKernelGGL(k_bn_stats, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, h, part, rpb);
+            hipLaunchKernelGGL(k_bn_apply, elementwise_grid(n * F), 256, sizeof(float) * 2 * F, st, n, F, cs, h, part, parts, rpb, m->eps, net.gamma,
+                               net.beta, c.xhat, y, c.stats);
             HIPCHK(hipGetLastError());
         }
         h = y;
@@ -2444,17 +2330,8 @@ int net_backward(hipStream_t st, Buf &buf, Net &net, const NetCache &c, float *d
         const int F = m->dims.back(), cs = column_shift(F);
         float *p_dyx = net.part + net.g_off[2 * L], *p_dy = net.part + net.g_off[2 * L + 1];
         const bool fuse = net.rate[L] == 0.0f && act_last != GNN_ACT_SOFTMAX;
-        const bool bn_small = !comm && bn_small_ok(n, F);
-        if (bn_small) {             // small batch: the two column sums and d x in one launch, into a new array
-            float *dx = nullptr;
-            if ((rc = buf.get(&dx, (size_t)n * F))) return rc;
-            hipLaunchKernelGGL(k_bn_bwd_small, elementwise_grid(n * F), 256, 0, st, n, F, cs, d, c.xhat, net.gamma, c.stats, m->eps, p_dyx, p_dy, ps, parts,
-                               c.a[L - 1], fuse ? act_last : -1, dx);
-            d = dx;
-        } else
         hipLaunchKernelGGL(k_colreduce2, dim3(cdiv(F, 1 << cs), parts), 256, 0, st, n, F, cs, d, c.xhat, p_dyx, p_dy, ps, rpb);
-        if (bn_small) {
-        } else if (comm) {
+        if (comm) {
             // this rank's sums [sum d y xhat | sum d y] (adjacent in the gradient vector: they ARE the gamma / beta gradients), those of
             // all ranks all-gathered, added in rank order by every block of the apply kernel
             float *loc = nullptr, *all = nullptr;
